@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- delay-grid log-marginal-likelihood evaluations per second on MI355X.
+
+Workload (BASELINE.json metric: N = 4096 total observations, 2 bands, Matern-3/2, fp64): synthetic
+irregularly sampled light curves 2 x 2048 (gpcc_amd.synthetic, seed 1), fixed hyper-parameters
+(alpha_l = var(y_l), rho = 3.5), a 1024-point delay grid tau_2 in linspace(0, 20, 1024) per GPU.
+One STEP = every rank evaluates its block of the grid through the C ABI
+(gpcc_loglik_batch_device: assemble K, Cholesky, solve, log-det -> one log-likelihood per delay),
+then ONE all_gather (RCCL) of the log-likelihoods and getprobabilities on the gathered vector.
+Weak scaling: the grid grows with the number of GPUs (1024 delays per GPU).
+
+Launch: python bench.py [--gpus 1]            or, for N > 1,
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+               --master-port P bench.py --gpus N --steps K --warmup W
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (vendor sheet; BASELINE.md "Bounds")
+TILE = 128
+
+
+def update_flops_per_eval(N):
+    """Algorithmic flops of the panel-update (dsyrk/dgemm) part of one N x N Cholesky, counted on the
+    lower triangle only: tiles (I,k), I>k get 2*128^3*k, diagonal tiles (dsyrk) 128^2*(128+1)*k ...
+    summed in closed form per step k (padded order nt*128)."""
+    nt = (N + TILE - 1) // TILE
+    total = 0.0
+    per_step = []
+    for k in range(1, nt):
+        K = k * TILE
+        f = (nt - k - 1) * 2.0 * TILE * TILE * K + TILE * (TILE + 1) * K   # gemm tiles + syrk diag tile
+        per_step.append(f)
+        total += f
+    return total, per_step
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid", type=int, default=1024, help="delays per GPU per step")
+    ap.add_argument("--n-per-band", type=int, default=2048)
+    ap.add_argument("--kernel", default="matern32")
+    ap.add_argument("--streams", type=int, default=None)
+    ap.add_argument("--slots", type=int, default=None)
+    ap.add_argument("--lds-dma", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="oracle evaluations in the CPU baseline (0: one per core)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import gpcc_amd
+    from gpcc_amd import synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    Nb = args.n_per_band
+    t, y, s, _ = synthetic.simulate_lightcurves([Nb, Nb], seed=1)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    N = 2 * Nb
+    G = args.grid
+    Gtot = G * world
+    grid_all = np.linspace(0.0, 20.0, Gtot)
+    lo = rank * G
+    delays = np.stack([np.zeros(G), grid_all[lo:lo + G]], 1)
+
+    obj = gpcc_amd.Objective(t, y, s, args.kernel, marginalise_b=True, precision="fp64", device=local,
+                             streams=args.streams, slots_per_stream=args.slots, lds_dma=args.lds_dma)
+    d_delays = torch.as_tensor(delays, device=dev).contiguous()
+    d_alpha = torch.as_tensor(np.tile(alpha, (G, 1)), device=dev).contiguous()
+    d_rho = torch.full((G,), float(rho), dtype=torch.float64, device=dev)
+    d_ll = torch.empty(G, dtype=torch.float64, device=dev)
+    d_info = torch.empty(G, dtype=torch.int32, device=dev)
+    d_all = torch.empty(Gtot, dtype=torch.float64, device=dev)
+    d_prob = torch.empty(Gtot, dtype=torch.float64, device=dev)
+    from gpcc_amd import _capi
+    lib = _capi.load()
+
+    def step():
+        obj.loglik_batch_device(d_delays, d_alpha, d_rho, out=d_ll, info=d_info)
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_ll)     # the path's single collective
+            src = d_all
+        else:
+            src = d_ll
+        _capi.check(lib.gpcc_probabilities_device(Gtot, src.data_ptr(), None, d_prob.data_ptr(),
+                                                  torch.cuda.current_stream(dev).cuda_stream))
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    info_bad = int((d_info != 0).sum().item())
+    psum = float(d_prob.sum().item())
+    value = Gtot * args.steps / elapsed
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        # dominant kernel = the fp64-MFMA panel update; its launches are timed live with HIP events
+        # on the stream they run on (gpcc_profile_*), groups serialised on one stream meanwhile.
+        obj.profile(True)
+        obj.profile_reset()
+        obj.loglik_batch_device(d_delays, d_alpha, d_rho, out=d_ll, info=d_info)
+        torch.cuda.synchronize(dev)
+        prof = obj.profile_get()
+        obj.profile(False)
+        launches, total_ms = prof["panel_update"]
+        flops_eval, _ = update_flops_per_eval(N)
+        if launches > 0 and total_ms > 0:
+            avg_ms = total_ms / launches
+            flops_per_launch = flops_eval * G / launches      # algorithmic flops / launch (average over steps k)
+            achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "gpcc_gemm_nt<false,*> (panel update)", "achieved": round(achieved, 3),
+                        "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
+                        "traffic": None, "launches": launches, "avg_launch_ms": round(avg_ms, 4),
+                        "algorithmic_flops_per_launch": flops_per_launch,
+                        "other_kernels_ms": {k: round(v[1], 3) for k, v in prof.items()}}
+            # the HBM-bound assembly kernel, reported beside it
+            an, ams = prof["assemble"]
+            nt = (N + TILE - 1) // TILE
+            abytes = 8.0 * TILE * TILE * nt * (nt + 1) / 2 * G / max(an, 1)
+            roofline["assemble"] = {"bound": "hbm", "achieved": round(abytes / (ams / max(an, 1) * 1e-3) / 1e9, 1),
+                                    "peak": 8000.0, "unit": "GB/s", "avg_launch_ms": round(ams / max(an, 1), 4),
+                                    "algorithmic_bytes_per_launch": abytes}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle   # the CPU restatement, timed as the reported baseline only
+        cores = len(os.sched_getaffinity(0))
+        nthreads = max(1, min(cores, oracle.max_threads()))
+        nsample = args.cpu_sample or nthreads
+        idx = np.linspace(0, G - 1, nsample).astype(int)
+        c0 = time.perf_counter()
+        ref, rinfo = oracle.loglik_batch(args.kernel, t, y, s, delays[idx], np.tile(alpha, (nsample, 1)),
+                                         np.full(nsample, rho), True, nthreads=nthreads)
+        cpu_s = time.perf_counter() - c0
+        gpu_ll = d_ll.cpu().numpy()[idx]
+        rel = float(np.max(np.abs(gpu_ll - ref) / np.abs(ref)))
+        cpu_baseline = {"value": round(nsample / cpu_s, 4), "unit": "evals/s", "cores": nthreads, "kind": "port",
+                        "sample": "%d of the %d grid delays, one per OpenMP thread (C restatement oracle/, "
+                                  "reference not executable: no Julia)" % (nsample, G),
+                        "seconds": round(cpu_s, 2), "max_rel_err_gpu_vs_cpu": rel}
+
+    if rank == 0:
+        out = {
+            "metric": "delay-grid loglik evals/sec (N=4096, 2-band Matern-3/2)",
+            "value": round(value, 2), "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "2-band synthetic N=%d per band (N=%d), %s fp64, %d-point delay grid per GPU"
+                                   % (Nb, N, args.kernel, G),
+                       "grid_total": Gtot, "streams": obj.get_option("streams"),
+                       "slots_per_stream": obj.get_option("slots_per_stream"), "lds_dma": obj.get_option("lds_dma"),
+                       "parallelism": "grid-sharded x%d, 1 all_gather" % world},
+            "info_nonzero": info_bad, "posterior_sum": psum,
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    obj.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

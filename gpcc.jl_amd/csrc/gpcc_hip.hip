@@ -1,0 +1,619 @@
+// gpcc_hip.hip -- host side of libgpcc_hip.so: the C ABI of include/gpcc_hip.h over the gfx950
+// kernels of gpcc_kernels.hip.h.  No CPU fallback: every compute entry needs a HIP device.
+#include "gpcc_kernels.hip.h"
+
+#include "../../include/gpcc_hip.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define GPCC_VERSION_NUMBER 100
+#define GPCC_MAX_STREAMS 8
+
+static thread_local std::string g_err;
+
+struct ProfRec { int which; hipEvent_t a, b; };
+
+struct gpcc_handle_s {
+    int device = 0;
+    int L = 0, N = 0, Np = 0, nt = 0, kernel_id = 0, mb = 1, precision = 0;
+    int Nl[GPCC_MAXL];
+    double mean_b[GPCC_MAXL], sigma_b[GPCC_MAXL];
+    std::vector<double> resid_host;
+    double *d_t = nullptr, *d_sig2 = nullptr, *d_resid = nullptr;
+    int *d_band = nullptr;
+    // options
+    int streams = 2, slots_per_stream = 64, lds_dma = 0;
+    // workspace
+    bool ws_ready = false;
+    int ws_streams = 0, ws_slots = 0;
+    double *d_tiles = nullptr, *d_linv = nullptr, *d_z = nullptr, *d_w = nullptr, *d_logdet = nullptr,
+           *d_quad = nullptr;
+    int *d_info = nullptr;
+    long slot_stride = 0;
+    hipStream_t str[GPCC_MAX_STREAMS] = {};
+    hipEvent_t ev_done[GPCC_MAX_STREAMS] = {};
+    hipEvent_t ev_start = nullptr;
+    hipStream_t main_stream = nullptr;
+    // staging for the host-pointer API
+    double *d_par = nullptr, *d_out = nullptr;
+    int *d_oinfo = nullptr;
+    long par_cap = 0;
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    long prof_n[GPCC_PROF_COUNT] = {};
+    double prof_ms[GPCC_PROF_COUNT] = {};
+    std::string err;
+};
+
+static int fail(gpcc_handle_t h, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return fail(h, GPCC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                                       \
+    } while (0)
+
+extern "C" int gpcc_version(void) { return GPCC_VERSION_NUMBER; }
+
+extern "C" const char *gpcc_last_error(gpcc_handle_t h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+static int set_device(gpcc_handle_t h, int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(h, GPCC_ERR_HIP, "no HIP device available (%s); libgpcc_hip has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(h, GPCC_ERR_ARGUMENT, "device_id %d out of range [0,%d)", device, n);
+    HIPCHK(h, hipSetDevice(device));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int gpcc_create(gpcc_handle_t *out, int L, const int *Nl, const double *t, const double *y,
+                           const double *sigma, int kernel_id, int marginalise_b, int precision, int device_id)
+{
+    if (!out) return fail(nullptr, GPCC_ERR_ARGUMENT, "handle pointer is NULL");
+    *out = nullptr;
+    if (L < 1 || L > GPCC_MAXL) return fail(nullptr, GPCC_ERR_ARGUMENT, "L=%d outside [1,%d]", L, GPCC_MAXL);
+    if (!Nl || !t || !y || !sigma) return fail(nullptr, GPCC_ERR_ARGUMENT, "NULL light-curve pointer");
+    if (kernel_id < 0 || kernel_id > 3) return fail(nullptr, GPCC_ERR_ARGUMENT, "unknown kernel_id %d", kernel_id);
+    if (precision == GPCC_PRECISION_FP32)
+        return fail(nullptr, GPCC_ERR_UNSUPPORTED, "fp32 precision is not implemented in this build");
+    if (precision != GPCC_PRECISION_FP64) return fail(nullptr, GPCC_ERR_ARGUMENT, "unknown precision %d", precision);
+    long N = 0;
+    for (int l = 0; l < L; ++l) {
+        if (Nl[l] < 1 || (marginalise_b && Nl[l] < 2))
+            return fail(nullptr, GPCC_ERR_ARGUMENT, "band %d has %d observations (need >= %d)", l + 1, Nl[l],
+                        marginalise_b ? 2 : 1);
+        N += Nl[l];
+    }
+    if (N > 65536) return fail(nullptr, GPCC_ERR_ARGUMENT, "N=%ld too large", N);
+    int rc = set_device(nullptr, device_id);
+    if (rc) return rc;
+
+    gpcc_handle_t h = new gpcc_handle_s();
+    h->device = device_id;
+    h->L = L;
+    h->N = (int)N;
+    h->nt = (int)((N + GPCC_TILE - 1) / GPCC_TILE);
+    h->Np = h->nt * GPCC_TILE;
+    h->kernel_id = kernel_id;
+    h->mb = marginalise_b ? 1 : 0;
+    h->precision = precision;
+    std::vector<double> ht(h->Np, 0.0), hs(h->Np, 0.0), hr(h->Np, 0.0);
+    std::vector<int> hb(h->Np, -1);
+    long off = 0;
+    for (int l = 0; l < L; ++l) {
+        h->Nl[l] = Nl[l];
+        // mu_b = mean(y_l), Sigma_b = 100 var(y_l) (n-1): marginaliseb.jl:92-94
+        double s = 0.0;
+        for (int n = 0; n < Nl[l]; ++n) s += y[off + n];
+        const double mean = s / Nl[l];
+        double v = 0.0;
+        for (int n = 0; n < Nl[l]; ++n) { const double d = y[off + n] - mean; v += d * d; }
+        h->mean_b[l] = mean;
+        h->sigma_b[l] = marginalise_b ? 100.0 * (v / (Nl[l] - 1)) : 0.0;
+        for (int n = 0; n < Nl[l]; ++n) {
+            ht[off + n] = t[off + n];
+            hs[off + n] = sigma[off + n] * sigma[off + n];  // Sobs = Diagonal(sigma.^2), :89
+            hr[off + n] = y[off + n] - mean;                // Y - bbar (bbar = Q mu_b / Q b)
+            hb[off + n] = l;
+        }
+        off += Nl[l];
+    }
+    h->resid_host.assign(hr.begin(), hr.begin() + N);
+#define CR(call)                                                                                             \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess) {                                                                              \
+            int r_ = fail(nullptr, GPCC_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));             \
+            gpcc_destroy(h);                                                                                 \
+            return r_;                                                                                       \
+        }                                                                                                    \
+    } while (0)
+    const size_t nb = sizeof(double) * h->Np;
+    CR(hipMalloc(&h->d_t, nb));
+    CR(hipMalloc(&h->d_sig2, nb));
+    CR(hipMalloc(&h->d_resid, nb));
+    CR(hipMalloc(&h->d_band, sizeof(int) * h->Np));
+    CR(hipMemcpy(h->d_t, ht.data(), nb, hipMemcpyHostToDevice));
+    CR(hipMemcpy(h->d_sig2, hs.data(), nb, hipMemcpyHostToDevice));
+    CR(hipMemcpy(h->d_resid, hr.data(), nb, hipMemcpyHostToDevice));
+    CR(hipMemcpy(h->d_band, hb.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice));
+    CR(hipStreamCreateWithFlags(&h->main_stream, hipStreamNonBlocking));
+    CR(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
+#undef CR
+    *out = h;
+    return 0;
+}
+
+static void free_workspace(gpcc_handle_t h)
+{
+    hipFree(h->d_tiles); hipFree(h->d_linv); hipFree(h->d_z); hipFree(h->d_w);
+    hipFree(h->d_logdet); hipFree(h->d_quad); hipFree(h->d_info);
+    h->d_tiles = h->d_linv = h->d_z = h->d_w = h->d_logdet = h->d_quad = nullptr;
+    h->d_info = nullptr;
+    for (int s = 0; s < GPCC_MAX_STREAMS; ++s) {
+        if (h->str[s]) { hipStreamDestroy(h->str[s]); h->str[s] = nullptr; }
+        if (h->ev_done[s]) { hipEventDestroy(h->ev_done[s]); h->ev_done[s] = nullptr; }
+    }
+    h->ws_ready = false;
+}
+
+extern "C" int gpcc_destroy(gpcc_handle_t h)
+{
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    for (auto &r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    free_workspace(h);
+    hipFree(h->d_t); hipFree(h->d_sig2); hipFree(h->d_resid); hipFree(h->d_band);
+    hipFree(h->d_par); hipFree(h->d_out); hipFree(h->d_oinfo);
+    if (h->main_stream) hipStreamDestroy(h->main_stream);
+    if (h->ev_start) hipEventDestroy(h->ev_start);
+    delete h;
+    return 0;
+}
+
+extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
+{
+    if (!h || !key) return fail(h, GPCC_ERR_ARGUMENT, "NULL handle/key");
+    if (!strcmp(key, "streams")) {
+        if (v < 1 || v > GPCC_MAX_STREAMS) return fail(h, GPCC_ERR_ARGUMENT, "streams must be in [1,%d]", GPCC_MAX_STREAMS);
+        h->streams = (int)v;
+    } else if (!strcmp(key, "slots_per_stream")) {
+        if (v < 1 || v > 4096) return fail(h, GPCC_ERR_ARGUMENT, "slots_per_stream must be in [1,4096]");
+        h->slots_per_stream = (int)v;
+    } else if (!strcmp(key, "lds_dma")) {
+        h->lds_dma = v ? 1 : 0;
+    } else {
+        return fail(h, GPCC_ERR_ARGUMENT, "unknown option '%s'", key);
+    }
+    return 0;
+}
+
+extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
+{
+    if (!h || !key) return -1;
+    if (!strcmp(key, "streams")) return h->streams;
+    if (!strcmp(key, "slots_per_stream")) return h->slots_per_stream;
+    if (!strcmp(key, "lds_dma")) return h->lds_dma;
+    if (!strcmp(key, "N")) return h->N;
+    if (!strcmp(key, "Np")) return h->Np;
+    if (!strcmp(key, "bytes_per_slot")) return (long)(((long)h->nt * (h->nt + 1) / 2 + 1) * GPCC_TILE_ELEMS + 2L * h->Np) * 8;
+    return -1;
+}
+
+extern "C" int gpcc_get_constants(gpcc_handle_t h, double *mean_b, double *Sigma_b, double *resid)
+{
+    if (!h) return fail(h, GPCC_ERR_ARGUMENT, "NULL handle");
+    if (mean_b) memcpy(mean_b, h->mean_b, sizeof(double) * h->L);
+    if (Sigma_b) memcpy(Sigma_b, h->sigma_b, sizeof(double) * h->L);
+    if (resid) memcpy(resid, h->resid_host.data(), sizeof(double) * h->N);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+static int ensure_workspace(gpcc_handle_t h)
+{
+    if (h->ws_ready && h->ws_streams == h->streams && h->ws_slots == h->slots_per_stream) return 0;
+    HIPCHK(h, hipDeviceSynchronize());
+    free_workspace(h);
+    const long slots = (long)h->streams * h->slots_per_stream;
+    h->slot_stride = ((long)h->nt * (h->nt + 1) / 2) * GPCC_TILE_ELEMS;
+    HIPCHK(h, hipMalloc(&h->d_tiles, sizeof(double) * h->slot_stride * slots));
+    HIPCHK(h, hipMalloc(&h->d_linv, sizeof(double) * GPCC_TILE_ELEMS * slots));
+    HIPCHK(h, hipMalloc(&h->d_z, sizeof(double) * h->Np * slots));
+    HIPCHK(h, hipMalloc(&h->d_w, sizeof(double) * h->Np * slots));
+    HIPCHK(h, hipMalloc(&h->d_logdet, sizeof(double) * slots));
+    HIPCHK(h, hipMalloc(&h->d_quad, sizeof(double) * slots));
+    HIPCHK(h, hipMalloc(&h->d_info, sizeof(int) * slots));
+    for (int s = 0; s < h->streams; ++s) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->str[s], hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_done[s], hipEventDisableTiming));
+    }
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_diag_factor, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  GPCC_DIAG_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_gemm_nt<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_gemm_nt<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_gemm_nt<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_gemm_nt<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    h->ws_streams = h->streams;
+    h->ws_slots = h->slots_per_stream;
+    h->ws_ready = true;
+    return 0;
+}
+
+static GpccCtx make_ctx(gpcc_handle_t h)
+{
+    GpccCtx c;
+    c.tiles = h->d_tiles; c.linv = h->d_linv; c.z = h->d_z; c.w = h->d_w;
+    c.logdet = h->d_logdet; c.quad = h->d_quad; c.info = h->d_info;
+    c.t = h->d_t; c.sig2 = h->d_sig2; c.resid = h->d_resid; c.band = h->d_band;
+    for (int l = 0; l < GPCC_MAXL; ++l) c.sigma_b[l] = (l < h->L) ? h->sigma_b[l] : 0.0;
+    c.slot_stride = h->slot_stride;
+    c.L = h->L; c.N = h->N; c.Np = h->Np; c.nt = h->nt; c.kernel_id = h->kernel_id; c.marginalise_b = h->mb;
+    return c;
+}
+
+struct ProfScope {
+    gpcc_handle_t h; int which; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(gpcc_handle_t h_, int w, hipStream_t s_) : h(h_), which(w), s(s_)
+    {
+        if (h->prof) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
+    }
+    ~ProfScope()
+    {
+        if (h->prof) { hipEventRecord(b, s); h->recs.push_back({which, a, b}); }
+    }
+};
+
+static void launch_assemble(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s)
+{
+    ProfScope p(h, GPCC_PROF_ASSEMBLE, s);
+    dim3 grid(c.nt * c.nt, g.cnt);
+    switch (c.kernel_id) {
+    case 0: gpcc_assemble_tiles<0><<<grid, 256, 0, s>>>(c, g); break;
+    case 1: gpcc_assemble_tiles<1><<<grid, 256, 0, s>>>(c, g); break;
+    case 2: gpcc_assemble_tiles<2><<<grid, 256, 0, s>>>(c, g); break;
+    default: gpcc_assemble_tiles<3><<<grid, 256, 0, s>>>(c, g); break;
+    }
+}
+
+// assemble + left-looking blocked Cholesky + fused forward solve for one group on stream s
+static int enqueue_group(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s, bool factor = true)
+{
+    launch_assemble(h, c, g, s);
+    if (!factor) return 0;
+    const int cnt8 = 8 * ((g.cnt + 7) / 8);
+    for (int k = 0; k < c.nt; ++k) {
+        if (k > 0) {
+            ProfScope p(h, GPCC_PROF_PANEL_UPDATE, s);
+            const int grid = cnt8 * (c.nt - k);
+            if (h->lds_dma) gpcc_gemm_nt<false, true><<<grid, 256, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
+            else gpcc_gemm_nt<false, false><<<grid, 256, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
+        }
+        {
+            ProfScope p(h, GPCC_PROF_DIAG, s);
+            gpcc_diag_factor<<<g.cnt, 256, GPCC_DIAG_LDS_BYTES, s>>>(c, g, k);
+        }
+        if (k < c.nt - 1) {
+            ProfScope p(h, GPCC_PROF_TRSM, s);
+            const int grid = cnt8 * (c.nt - k - 1);
+            if (h->lds_dma) gpcc_gemm_nt<true, true><<<grid, 256, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
+            else gpcc_gemm_nt<true, false><<<grid, 256, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
+        }
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, GPCC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int gpcc_loglik_batch_device(gpcc_handle_t h, int M, const double *d_delays, const double *d_alpha,
+                                        const double *d_rho, double *d_loglik, int *d_info, void *stream)
+{
+    if (!h) return fail(h, GPCC_ERR_ARGUMENT, "NULL handle");
+    if (M < 0) return fail(h, GPCC_ERR_ARGUMENT, "M=%d < 0", M);
+    if (M == 0) return 0;
+    if (!d_delays || !d_alpha || !d_rho || !d_loglik || !d_info) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
+    int rc = set_device(h, h->device);
+    if (rc) return rc;
+    rc = ensure_workspace(h);
+    if (rc) return rc;
+    hipStream_t caller = (hipStream_t)stream;
+    const GpccCtx c = make_ctx(h);
+    const int S = h->prof ? 1 : h->streams;  // profiling serialises groups onto one stream
+    const int cs = h->slots_per_stream;
+    const int ngroups = (M + cs - 1) / cs;
+    const int used = ngroups < S ? ngroups : S;
+    HIPCHK(h, hipEventRecord(h->ev_start, caller));
+    for (int s = 0; s < used; ++s) HIPCHK(h, hipStreamWaitEvent(h->str[s], h->ev_start, 0));
+    for (int gi = 0; gi < ngroups; ++gi) {
+        const int s = gi % S;
+        GpccGroup g;
+        g.delays = d_delays; g.alpha = d_alpha; g.rho = d_rho;
+        g.out_loglik = d_loglik; g.out_info = d_info;
+        g.first = gi * cs;
+        g.slot0 = s * cs;
+        g.cnt = (M - g.first < cs) ? (M - g.first) : cs;
+        rc = enqueue_group(h, c, g, h->str[s]);
+        if (rc) return rc;
+    }
+    for (int s = 0; s < used; ++s) {
+        HIPCHK(h, hipEventRecord(h->ev_done[s], h->str[s]));
+        HIPCHK(h, hipStreamWaitEvent(caller, h->ev_done[s], 0));
+    }
+    return 0;
+}
+
+static int ensure_staging(gpcc_handle_t h, long M)
+{
+    if (M <= h->par_cap) return 0;
+    hipFree(h->d_par); hipFree(h->d_out); hipFree(h->d_oinfo);
+    h->d_par = h->d_out = nullptr; h->d_oinfo = nullptr; h->par_cap = 0;
+    HIPCHK(h, hipMalloc(&h->d_par, sizeof(double) * M * (2 * h->L + 1)));
+    HIPCHK(h, hipMalloc(&h->d_out, sizeof(double) * M));
+    HIPCHK(h, hipMalloc(&h->d_oinfo, sizeof(int) * M));
+    h->par_cap = M;
+    return 0;
+}
+
+extern "C" int gpcc_loglik_batch(gpcc_handle_t h, int M, const double *delays, const double *alpha,
+                                 const double *rho, double *loglik, int *info)
+{
+    if (!h) return fail(h, GPCC_ERR_ARGUMENT, "NULL handle");
+    if (M < 0) return fail(h, GPCC_ERR_ARGUMENT, "M=%d < 0", M);
+    if (M == 0) return 0;
+    if (!delays || !alpha || !rho || !loglik || !info) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
+    int rc = set_device(h, h->device);
+    if (rc) return rc;
+    rc = ensure_staging(h, M);
+    if (rc) return rc;
+    const long ML = (long)M * h->L;
+    double *dd = h->d_par, *da = h->d_par + ML, *dr = h->d_par + 2 * ML;
+    HIPCHK(h, hipMemcpyAsync(dd, delays, sizeof(double) * ML, hipMemcpyHostToDevice, h->main_stream));
+    HIPCHK(h, hipMemcpyAsync(da, alpha, sizeof(double) * ML, hipMemcpyHostToDevice, h->main_stream));
+    HIPCHK(h, hipMemcpyAsync(dr, rho, sizeof(double) * M, hipMemcpyHostToDevice, h->main_stream));
+    rc = gpcc_loglik_batch_device(h, M, dd, da, dr, h->d_out, h->d_oinfo, h->main_stream);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(loglik, h->d_out, sizeof(double) * M, hipMemcpyDeviceToHost, h->main_stream));
+    HIPCHK(h, hipMemcpyAsync(info, h->d_oinfo, sizeof(int) * M, hipMemcpyDeviceToHost, h->main_stream));
+    HIPCHK(h, hipStreamSynchronize(h->main_stream));
+    return 0;
+}
+
+// one evaluation into slot 0, then a dense export (symmetric K, or the factor L)
+static int single_eval_export(gpcc_handle_t h, const double *delays, const double *alpha, double rho, double *out,
+                              int *info, bool factor)
+{
+    if (!h || !delays || !alpha || !out) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
+    int rc = set_device(h, h->device);
+    if (rc) return rc;
+    rc = ensure_workspace(h);
+    if (rc) return rc;
+    rc = ensure_staging(h, 1);
+    if (rc) return rc;
+    for (int l = 0; l < h->L; ++l)
+        if (!(alpha[l] > 0.0)) return fail(h, GPCC_ERR_ARGUMENT, "AssertionError: all(scale .> 0)");
+    if (rho <= 0.0) return fail(h, GPCC_ERR_ARGUMENT, "ρ=%.8f is <= 0", rho);
+    hipStream_t s = h->str[0];
+    double *dd = h->d_par, *da = h->d_par + h->L, *dr = h->d_par + 2 * h->L;
+    HIPCHK(h, hipMemcpyAsync(dd, delays, sizeof(double) * h->L, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(da, alpha, sizeof(double) * h->L, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(dr, &rho, sizeof(double), hipMemcpyHostToDevice, s));
+    const GpccCtx c = make_ctx(h);
+    GpccGroup g;
+    g.delays = dd; g.alpha = da; g.rho = dr; g.out_loglik = h->d_out; g.out_info = h->d_oinfo;
+    g.first = 0; g.slot0 = 0; g.cnt = 1;
+    const bool was_prof = h->prof;
+    h->prof = false;
+    rc = enqueue_group(h, c, g, s, factor);
+    h->prof = was_prof;
+    if (rc) return rc;
+    double *d_dense = nullptr;
+    const long nn = (long)h->N * h->N;
+    HIPCHK(h, hipMalloc(&d_dense, sizeof(double) * nn));
+    gpcc_export_dense<<<(unsigned)((nn + 255) / 256), 256, 0, s>>>(c, 0, d_dense, factor ? 0 : 1);
+    hipError_t e = hipMemcpyAsync(out, d_dense, sizeof(double) * nn, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && factor && info) e = hipMemcpyAsync(info, h->d_oinfo, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    hipFree(d_dense);
+    if (e != hipSuccess) return fail(h, GPCC_ERR_HIP, "dense export failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int gpcc_model_matrix(gpcc_handle_t h, const double *delays, const double *alpha, double rho, double *K_out)
+{
+    return single_eval_export(h, delays, alpha, rho, K_out, nullptr, false);
+}
+
+extern "C" int gpcc_factor_dense(gpcc_handle_t h, const double *delays, const double *alpha, double rho,
+                                 double *L_out, int *info)
+{
+    return single_eval_export(h, delays, alpha, rho, L_out, info, true);
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int gpcc_covariance(int kernel_id, int L, const double *scale, const double *delays, double rho,
+                               const int *Nx, const double *x, const int *Ny, const double *y, double *out,
+                               int device_id)
+{
+    if (kernel_id < 0 || kernel_id > 3) return fail(nullptr, GPCC_ERR_ARGUMENT, "unknown kernel_id %d", kernel_id);
+    if (L < 1 || !scale || !delays || !Nx || !x || !Ny || !y || !out)
+        return fail(nullptr, GPCC_ERR_ARGUMENT, "bad argument");
+    for (int l = 0; l < L; ++l)
+        if (!(scale[l] > 0.0)) return fail(nullptr, GPCC_ERR_ARGUMENT, "AssertionError: all(scale .> 0)");
+    if (rho <= 0.0) return fail(nullptr, GPCC_ERR_ARGUMENT, "ρ=%.8f is <= 0", rho);
+    int rc = set_device(nullptr, device_id);
+    if (rc) return rc;
+    long nx = 0, ny = 0;
+    for (int l = 0; l < L; ++l) {
+        if (Nx[l] < 0 || Ny[l] < 0) return fail(nullptr, GPCC_ERR_ARGUMENT, "negative band length");
+        nx += Nx[l]; ny += Ny[l];
+    }
+    if (nx == 0 || ny == 0) return 0;
+    // shifted times x - delays[band] and per-point scales (delayedCovariance.jl:27)
+    std::vector<double> hx(2 * nx), hy(2 * ny);
+    long o = 0;
+    for (int l = 0; l < L; ++l)
+        for (int n = 0; n < Nx[l]; ++n, ++o) { hx[o] = x[o] - delays[l]; hx[nx + o] = scale[l]; }
+    o = 0;
+    for (int l = 0; l < L; ++l)
+        for (int n = 0; n < Ny[l]; ++n, ++o) { hy[o] = y[o] - delays[l]; hy[ny + o] = scale[l]; }
+    double *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    hipError_t e = hipMalloc(&dx, sizeof(double) * 2 * nx);
+    if (e == hipSuccess) e = hipMalloc(&dy, sizeof(double) * 2 * ny);
+    if (e == hipSuccess) e = hipMalloc(&dout, sizeof(double) * nx * ny);
+    if (e == hipSuccess) e = hipMemcpy(dx, hx.data(), sizeof(double) * 2 * nx, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dy, hy.data(), sizeof(double) * 2 * ny, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const unsigned grid = (unsigned)((nx * ny + 255) / 256);
+        switch (kernel_id) {
+        case 0: gpcc_covariance_kernel<0><<<grid, 256>>>(nx, ny, dx, dx + nx, dy, dy + ny, rho, dout); break;
+        case 1: gpcc_covariance_kernel<1><<<grid, 256>>>(nx, ny, dx, dx + nx, dy, dy + ny, rho, dout); break;
+        case 2: gpcc_covariance_kernel<2><<<grid, 256>>>(nx, ny, dx, dx + nx, dy, dy + ny, rho, dout); break;
+        default: gpcc_covariance_kernel<3><<<grid, 256>>>(nx, ny, dx, dx + nx, dy, dy + ny, rho, dout); break;
+        }
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dout, sizeof(double) * nx * ny, hipMemcpyDeviceToHost);
+    hipFree(dx); hipFree(dy); hipFree(dout);
+    if (e != hipSuccess) return fail(nullptr, GPCC_ERR_HIP, "gpcc_covariance: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int gpcc_probabilities_device(int G, const double *d_loglik, const double *d_logprior, double *d_out,
+                                         void *stream)
+{
+    if (G <= 0 || !d_loglik || !d_out) return fail(nullptr, GPCC_ERR_ARGUMENT, "bad argument");
+    gpcc_probabilities_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(G, d_loglik, d_logprior, d_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, GPCC_ERR_HIP, "gpcc_probabilities: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int gpcc_probabilities(int G, const double *loglik, const double *logprior, double *out, int device_id)
+{
+    if (G <= 0 || !loglik || !out) return fail(nullptr, GPCC_ERR_ARGUMENT, "bad argument");
+    int rc = set_device(nullptr, device_id);
+    if (rc) return rc;
+    double *d = nullptr;
+    hipError_t e = hipMalloc(&d, sizeof(double) * 3 * (size_t)G);
+    if (e == hipSuccess) e = hipMemcpy(d, loglik, sizeof(double) * G, hipMemcpyHostToDevice);
+    if (e == hipSuccess && logprior) e = hipMemcpy(d + G, logprior, sizeof(double) * G, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = gpcc_probabilities_device(G, d, logprior ? d + G : nullptr, d + 2 * (size_t)G, nullptr);
+        if (rc) { hipFree(d); return rc; }
+        e = hipMemcpy(out, d + 2 * (size_t)G, sizeof(double) * G, hipMemcpyDeviceToHost);
+    }
+    hipFree(d);
+    if (e != hipSuccess) return fail(nullptr, GPCC_ERR_HIP, "gpcc_probabilities: %s", hipGetErrorString(e));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+static void prof_collect(gpcc_handle_t h)
+{
+    if (h->recs.empty()) return;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    for (auto &r : h->recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { h->prof_n[r.which] += 1; h->prof_ms[r.which] += ms; }
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    h->recs.clear();
+}
+
+extern "C" int gpcc_profile_enable(gpcc_handle_t h, int on)
+{
+    if (!h) return fail(h, GPCC_ERR_ARGUMENT, "NULL handle");
+    prof_collect(h);
+    h->prof = on != 0;
+    return 0;
+}
+
+extern "C" int gpcc_profile_reset(gpcc_handle_t h)
+{
+    if (!h) return fail(h, GPCC_ERR_ARGUMENT, "NULL handle");
+    prof_collect(h);
+    for (int i = 0; i < GPCC_PROF_COUNT; ++i) { h->prof_n[i] = 0; h->prof_ms[i] = 0.0; }
+    return 0;
+}
+
+extern "C" int gpcc_profile_get(gpcc_handle_t h, int which, long *launches, double *total_ms)
+{
+    if (!h || which < 0 || which >= GPCC_PROF_COUNT) return fail(h, GPCC_ERR_ARGUMENT, "bad argument");
+    prof_collect(h);
+    if (launches) *launches = h->prof_n[which];
+    if (total_ms) *total_ms = h->prof_ms[which];
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int gpcc_selftest(int device_id, double *tflops)
+{
+    int rc = set_device(nullptr, device_id);
+    if (rc) return rc;
+    double hA[64], hB[64], hD[256], ref[256];
+    for (int i = 0; i < 16; ++i)
+        for (int kk = 0; kk < 4; ++kk) hA[i * 4 + kk] = (double)(1 + i * 5 + kk * 3);  // asymmetric integers
+    for (int kk = 0; kk < 4; ++kk)
+        for (int j = 0; j < 16; ++j) hB[kk * 16 + j] = (double)(2 + kk * 7 - j * 2);
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+            double s = 0.0;
+            for (int kk = 0; kk < 4; ++kk) s += hA[i * 4 + kk] * hB[kk * 16 + j];
+            ref[i * 16 + j] = s;
+        }
+    double *d = nullptr;
+    HIPCHK(nullptr, hipMalloc(&d, sizeof(double) * (64 + 64 + 256)));
+    hipError_t e = hipMemcpy(d, hA, sizeof hA, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + 64, hB, sizeof hB, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        gpcc_selftest_map<<<1, 64>>>(d, d + 64, d + 128);
+        e = hipMemcpy(hD, d + 128, sizeof hD, hipMemcpyDeviceToHost);
+    }
+    if (e != hipSuccess) { hipFree(d); return fail(nullptr, GPCC_ERR_HIP, "selftest: %s", hipGetErrorString(e)); }
+    int bad = 0;
+    for (int i = 0; i < 256; ++i)
+        if (hD[i] != ref[i]) ++bad;
+    if (bad) { hipFree(d); return fail(nullptr, GPCC_ERR_STATE, "f64 MFMA fragment map mismatch in %d of 256 elements", bad); }
+    if (tflops) {
+        const int iters = 20000, blocks = 2048;
+        hipEvent_t a, b;
+        hipEventCreate(&a); hipEventCreate(&b);
+        gpcc_selftest_rate<<<blocks, 256>>>(d, 100);  // warm-up
+        hipEventRecord(a, 0);
+        gpcc_selftest_rate<<<blocks, 256>>>(d, iters);
+        hipEventRecord(b, 0);
+        e = hipEventSynchronize(b);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, a, b);
+        hipEventDestroy(a); hipEventDestroy(b);
+        const double flops = (double)blocks * 4 /*waves*/ * iters * 4 /*mfma*/ * 2048.0;
+        *tflops = (e == hipSuccess && ms > 0) ? flops / (ms * 1e-3) / 1e12 : 0.0;
+    }
+    hipFree(d);
+    return 0;
+}

@@ -1,0 +1,516 @@
+// gpcc_kernels.hip.h -- device code of libgpcc_hip.so (gfx950 / CDNA4 only).
+//
+// Data layout in HBM (DESIGN.md "Layout"): every evaluation owns one SLOT.  A slot stores the
+// lower triangle of its padded Np x Np matrix (Np = nt*128) as nt(nt+1)/2 TILES of 128x128
+// doubles; tile (I,J), J<=I, sits at ((I(I+1)/2)+J)*16384.  Inside a tile the 128 columns are
+// cut into 8 CHUNKS of 16; a chunk is 128 rows x 16 columns stored row-major = one contiguous
+// 16 KiB block that is copied 1:1 into LDS (register staging or LDS-DMA) and from which the
+// f64 MFMA fragments are read with two ds_read_b128 per fragment.  A row of tiles (I,0..I) is
+// contiguous, so both operand streams of the left-looking update are purely sequential reads.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#define GPCC_TILE 128
+#define GPCC_KC 16
+#define GPCC_CHUNK (GPCC_TILE * GPCC_KC)        /* 2048 doubles = 16 KiB */
+#define GPCC_TILE_ELEMS (GPCC_TILE * GPCC_TILE) /* 16384 doubles = 128 KiB */
+#define GPCC_MAXL 8
+#define GPCC_DIAG_LD 129
+#define GPCC_DIAG_LDS_BYTES ((GPCC_TILE * GPCC_DIAG_LD + 3 * GPCC_TILE + 256) * 8 + 16)
+#define GPCC_GEMM_LDS_BYTES (2 * 2 * GPCC_CHUNK * 8)
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+struct GpccCtx {
+    double *tiles;   // slots x slot_stride
+    double *linv;    // slots x 16384 : inverse of the current diagonal block, tile layout
+    double *z;       // slots x Np    : running right-hand side  r - L[:, :k] w[:k]
+    double *w;       // slots x Np    : w = L^-1 r
+    double *logdet;  // slots         : sum_i log L_ii
+    double *quad;    // slots         : |w|^2
+    int *info;       // slots
+    const double *t, *sig2, *resid;  // Np (padding: 0)
+    const int *band;                 // Np (padding: -1)
+    double sigma_b[GPCC_MAXL];
+    long slot_stride;
+    int L, N, Np, nt, kernel_id, marginalise_b;
+};
+
+struct GpccGroup {
+    const double *delays, *alpha, *rho;  // whole-batch arrays (M x L, M x L, M)
+    double *out_loglik;                  // whole-batch outputs
+    int *out_info;
+    int first;  // index of this group's first evaluation in the batch arrays
+    int slot0;  // first slot of the stream that runs this group
+    int cnt;    // evaluations in this group
+};
+
+__device__ __forceinline__ long gpcc_tile_off(int I, int J)
+{
+    return ((long)I * (I + 1) / 2 + J) * GPCC_TILE_ELEMS;
+}
+__device__ __forceinline__ int gpcc_elem_off(int r, int col)
+{
+    return (col >> 4) * GPCC_CHUNK + r * GPCC_KC + (col & 15);
+}
+
+// ------------------------------------------------------------------------------------------
+// Stationary kernels, /root/reference/src/util.jl:15-52, operation order kept (no contraction)
+// so that the element matches the CPU evaluation to the last bit up to exp()'s own rounding.
+// ------------------------------------------------------------------------------------------
+template <int KID>
+__device__ __forceinline__ double gpcc_kernel_eval(double xi, double xj, double rho)
+{
+#pragma clang fp contract(off)
+    if (KID == 0) {  // OU: exp(-|xi-xj|/rho)
+        double r = fabs(xi - xj);
+        return exp(-r / rho);
+    } else if (KID == 1) {  // rbf: exp(-0.5 (xi-xj)^2 / (2 rho))  -- rho linear, as the reference
+        double d = xi - xj;
+        return exp(-0.5 * (d * d) / (2.0 * rho));
+    } else if (KID == 2) {  // matern32
+        double r = fabs(xi - xj);
+        const double s3 = 1.7320508075688772;  // sqrt(3.0)
+        return (1.0 + s3 * r / rho) * exp(-s3 * r / rho);
+    } else {  // matern52
+        double r = fabs(xi - xj);
+        const double s5 = 2.23606797749979;  // sqrt(5.0)
+        return (1.0 + s5 * r / rho + (5.0 * (r * r)) / (3.0 * (rho * rho))) * exp(-s5 * r / rho);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// gpcc_assemble_tiles: K = delayedCovariance + Sobs + B for `cnt` evaluations, written once,
+// lower-triangle tiles only, 16 B per lane fully coalesced (a workgroup store instruction
+// covers 4 KiB contiguous).  HBM-write-bound: 8 * 128*128 * nt(nt+1)/2 bytes per evaluation.
+// Replaces delayedCovariance.jl:23-31 + marginaliseb.jl:135 (+ Sobs + B) + :137 (symmetrise:
+// a no-op, K is exactly symmetric, so only the lower triangle is materialised).
+// grid (nt*nt, cnt), block 256.
+// ------------------------------------------------------------------------------------------
+template <int KID>
+__global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup g)
+{
+    const int I = blockIdx.x / c.nt, J = blockIdx.x % c.nt;
+    if (J > I) return;
+    const int m = blockIdx.y, slot = g.slot0 + m, tid = threadIdx.x;
+    const double *delays = g.delays + (long)(g.first + m) * c.L;
+    const double *alpha = g.alpha + (long)(g.first + m) * c.L;
+    const double rho = g.rho[g.first + m];
+
+    __shared__ double su[2][GPCC_TILE], sa[2][GPCC_TILE], ssig[GPCC_TILE], ssb[GPCC_MAXL];
+    __shared__ int sb[2][GPCC_TILE];
+    if (tid < GPCC_MAXL) ssb[tid] = (tid < c.L) ? c.sigma_b[tid] : 0.0;
+
+    if (I == 0 && tid == 0) {  // per-slot state + the reference's argument checks
+        int bad = 0;
+        for (int l = 0; l < c.L; ++l)
+            if (!(alpha[l] > 0.0)) bad = -1;  // delayedCovariance.jl:3
+        if (bad == 0 && rho <= 0.0) bad = -2;  // delayedCovariance.jl:5-7
+        c.info[slot] = bad;
+        c.logdet[slot] = 0.0;
+        c.quad[slot] = 0.0;
+    }
+    {
+        const int side = tid >> 7, r = tid & 127;
+        const int gi = (side ? J : I) * GPCC_TILE + r;
+        const int b = c.band[gi];
+        sb[side][r] = b;
+        su[side][r] = (b >= 0) ? c.t[gi] - delays[b] : 0.0;  // x - delays[i], delayedCovariance.jl:27
+        sa[side][r] = (b >= 0) ? alpha[b] : 0.0;
+        if (side == 0) {
+            ssig[r] = c.sig2[gi];
+            if (I == J) c.z[(long)slot * c.Np + gi] = c.resid[gi];  // z <- Y - bbar
+        }
+    }
+    __syncthreads();
+
+    double *T = c.tiles + (long)slot * c.slot_stride + gpcc_tile_off(I, J);
+    const bool diag = (I == J);
+    const bool mb = c.marginalise_b != 0;
+#pragma unroll 4
+    for (int it = 0; it < 32; ++it) {
+        const int e = tid + 256 * it;  // 16-byte piece index inside the tile
+        const int ch = e >> 10, rem = e & 1023, r = rem >> 3, col = ch * 16 + (rem & 7) * 2;
+        d2 v;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma clang fp contract(off)
+            const int cc = col + h;
+            const int br = sb[0][r], bc = sb[1][cc];
+            double val;
+            if (br < 0 || bc < 0) {
+                val = (diag && r == cc) ? 1.0 : 0.0;  // identity padding: log 1 = 0, resid 0
+            } else {
+                const double kv = gpcc_kernel_eval<KID>(su[0][r], su[1][cc], rho);
+                val = (sa[0][r] * sa[1][cc]) * kv;
+                if (diag && r == cc) val = val + ssig[r];      // + Sobs
+                if (mb && br == bc) val = val + ssb[br];        // + B = Q Sigma_b Q'
+            }
+            v[h] = val;
+        }
+        *(d2 *)(T + (long)e * 2) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// gpcc_gemm_nt<TRSM, DMA>: the fp64 MFMA kernel.  One workgroup (4 waves, each a 64x64
+// quadrant = 4x4 v_mfma_f64_16x16x4_f64 accumulators) produces one 128x128 tile.
+//   TRSM == false (panel update, step k, tile I>=k):  T(I,k) -= sum_{j<k} L(I,j) L(k,j)^T
+//       K-loop over the 8k chunks of the two contiguous tile rows I and k.
+//   TRSM == true  (panel solve, step k, tile I>k):     L(I,k) = T(I,k) inv(L_kk)^T  and
+//       z_I -= L(I,k) w_k (the forward substitution of logpdf's whitening, fused).
+// Together these replace LAPACK dpotrf's dsyrk/dgemm/dtrsm inside cholesky(K)
+// (reached from marginaliseb.jl:139 via Distributions/PDMats).
+// Operands are staged through a 2-deep LDS ring (64 KiB), by registers or by LDS-DMA.
+// Blocks of one evaluation share blockIdx % 8, i.e. an XCD and its L2, because they all
+// stream the same tile row k.
+// ------------------------------------------------------------------------------------------
+template <bool TRSM, bool DMA>
+__global__ __launch_bounds__(256, 2) void gpcc_gemm_nt(GpccCtx c, GpccGroup g, int k)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, q = lane >> 4;
+
+    const int per = TRSM ? (c.nt - k - 1) : (c.nt - k);
+    const int x = blockIdx.x & 7, qq = blockIdx.x >> 3;
+    const int m = (qq / per) * 8 + x;
+    if (m >= g.cnt) return;
+    const int I = (TRSM ? k + 1 : k) + qq % per;
+    const int slot = g.slot0 + m;
+    if (c.info[slot] != 0) return;
+
+    double *tiles = c.tiles + (long)slot * c.slot_stride;
+    const double *gA = tiles + (TRSM ? gpcc_tile_off(I, k) : gpcc_tile_off(I, 0));
+    const double *gB = TRSM ? (c.linv + (long)slot * GPCC_TILE_ELEMS) : (tiles + gpcc_tile_off(k, 0));
+    const int nch = TRSM ? 8 : 8 * k;
+
+    // f64 16x16x4 C/D map: col = lane&15, row = (lane>>4) + 4*reg  (checked by gpcc_selftest)
+    double *T = tiles + gpcc_tile_off(I, k);
+    d4 acc[4][4];
+    if (TRSM) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+    } else {
+        // acc starts at -T(I,k): the epilogue is then a pure store of -acc (no read-modify-write)
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[fm][fn][r] = -T[(wc * 4 + fn) * GPCC_CHUNK + (wr * 64 + fm * 16 + q + 4 * r) * GPCC_KC + lr];
+    }
+
+    d2 ra[4], rb[4];
+    auto gload = [&](int ch) {
+        const d2 *pa = (const d2 *)(gA + (long)ch * GPCC_CHUNK);
+        const d2 *pb = (const d2 *)(gB + (long)ch * GPCC_CHUNK);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ra[i] = pa[tid + 256 * i]; rb[i] = pb[tid + 256 * i]; }
+    };
+    auto sstore = [&](int buf) {
+        d2 *sA = (d2 *)(smem + buf * 2 * GPCC_CHUNK);
+        d2 *sB = (d2 *)(smem + buf * 2 * GPCC_CHUNK + GPCC_CHUNK);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sA[tid + 256 * i] = ra[i]; sB[tid + 256 * i] = rb[i]; }
+    };
+    auto dma = [&](int ch, int buf) {
+        // one wave-instruction moves 1 KiB: LDS destination = wave-uniform base + lane*16
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave * 4 + i;
+            const double *srcA = gA + (long)ch * GPCC_CHUNK + piece * 128 + lane * 2;
+            const double *srcB = gB + (long)ch * GPCC_CHUNK + piece * 128 + lane * 2;
+            double *dstA = smem + buf * 2 * GPCC_CHUNK + piece * 128;
+            double *dstB = dstA + GPCC_CHUNK;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)srcA,
+                                             (__attribute__((address_space(3))) void *)dstA, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)srcB,
+                                             (__attribute__((address_space(3))) void *)dstB, 16, 0, 0);
+        }
+    };
+    auto compute = [&](int buf) {
+        const double *sA = smem + buf * 2 * GPCC_CHUNK;
+        const double *sB = sA + GPCC_CHUNK;
+        d2 a[4][2], b[4][2];
+        // lane (lr, q) holds k = 4q..4q+3 of its row: the MFMA sums over q, the 4 steps over s
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const d2 *pa = (const d2 *)(sA + (wr * 64 + f * 16 + lr) * GPCC_KC + 4 * q);
+            const d2 *pb = (const d2 *)(sB + (wc * 64 + f * 16 + lr) * GPCC_KC + 4 * q);
+            a[f][0] = pa[0]; a[f][1] = pa[1];
+            b[f][0] = pb[0]; b[f][1] = pb[1];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+                for (int fn = 0; fn < 4; ++fn)
+                    acc[fm][fn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[fm][s >> 1][s & 1], b[fn][s >> 1][s & 1],
+                                                                       acc[fm][fn], 0, 0, 0);
+    };
+
+    if (DMA) {
+        dma(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int ch = 0; ch < nch; ++ch) {
+            if (ch + 1 < nch) dma(ch + 1, (ch + 1) & 1);
+            compute(ch & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
+        gload(0);
+        sstore(0);
+        __syncthreads();
+        for (int ch = 0; ch < nch; ++ch) {
+            if (ch + 1 < nch) gload(ch + 1);
+            compute(ch & 1);
+            if (ch + 1 < nch) sstore((ch + 1) & 1);
+            __syncthreads();
+        }
+    }
+
+    if (!TRSM) {
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    T[(wc * 4 + fn) * GPCC_CHUNK + (wr * 64 + fm * 16 + q + 4 * r) * GPCC_KC + lr] = -acc[fm][fn][r];
+    } else {
+        double wv[4];
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) wv[fn] = c.w[(long)slot * c.Np + k * GPCC_TILE + wc * 64 + fn * 16 + lr];
+        double *red = smem;  // [2][128]; the operand ring is dead after the last barrier
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int R = wr * 64 + fm * 16 + q + 4 * r;
+                double p = 0.0;
+#pragma unroll
+                for (int fn = 0; fn < 4; ++fn) {
+                    const double xv = acc[fm][fn][r];
+                    T[(wc * 4 + fn) * GPCC_CHUNK + R * GPCC_KC + lr] = xv;
+                    p += xv * wv[fn];
+                }
+                p += __shfl_xor(p, 1);
+                p += __shfl_xor(p, 2);
+                p += __shfl_xor(p, 4);
+                p += __shfl_xor(p, 8);
+                if (lr == 0) red[wc * 128 + R] = p;
+            }
+        __syncthreads();
+        if (tid < 128) {
+            double *zp = c.z + (long)slot * c.Np + I * GPCC_TILE + tid;
+            *zp = *zp - (red[tid] + red[128 + tid]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// gpcc_diag_factor: step k's 128x128 diagonal block, one workgroup per evaluation, all in LDS:
+// potf2 (dpotf2), its triangular inverse (feeds the MFMA panel solve), sum log L_ii (logdet of
+// PDMat), w_k = inv(L_kk) z_k and |w_k|^2 (sqmahal); the last step writes
+// loglik = -(N log 2pi + 2 sum log L_ii)/2 - |w|^2/2  (Distributions.logpdf, marginaliseb.jl:139).
+// The scaled column j of L is parked in the upper triangle (row j), so the raw column can still
+// be read by the trailing update of the same step: one barrier per column.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, int k)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *sT = smem;                           // 128 x 129
+    double *sD = sT + GPCC_TILE * GPCC_DIAG_LD;  // L_jj
+    double *sI = sD + GPCC_TILE;                 // 1 / L_jj
+    double *sz = sI + GPCC_TILE;                 // z_k, later w_k
+    double *sr = sz + GPCC_TILE;                 // 256 reduction scratch
+    int *sbad = (int *)(sr + 256);
+
+    const int tid = threadIdx.x, m = blockIdx.x, slot = g.slot0 + m;
+    const bool last = (k == c.nt - 1);
+    const int inf = c.info[slot];
+    if (inf != 0) {
+        if (last && tid == 0) {
+            g.out_loglik[g.first + m] = __builtin_nan("");
+            g.out_info[g.first + m] = inf;
+        }
+        return;
+    }
+    const int ty = tid >> 4, tx = tid & 15;
+    double *tiles = c.tiles + (long)slot * c.slot_stride;
+    double *T = tiles + gpcc_tile_off(k, k);
+    for (int e = tid; e < GPCC_TILE_ELEMS; e += 256) {
+        const int ch = e >> 11, rem = e & 2047, r = rem >> 4, kk = rem & 15;
+        sT[r * GPCC_DIAG_LD + ch * 16 + kk] = T[e];
+    }
+    if (tid < GPCC_TILE) sz[tid] = c.z[(long)slot * c.Np + k * GPCC_TILE + tid];
+    if (tid == 0) *sbad = 0;
+
+    // ---- potf2, right-looking, one barrier per column
+    for (int j = 0; j < GPCC_TILE; ++j) {
+        __syncthreads();
+        const double d = sT[j * GPCC_DIAG_LD + j];
+        if (!(d > 0.0) && tid == 0 && *sbad == 0) *sbad = j + 1;  // also catches NaN
+        const double s = sqrt(d), inv = 1.0 / s, invd = 1.0 / d;
+        if (tid == 0) { sD[j] = s; sI[j] = inv; }
+        for (int i = j + 1 + tid; i < GPCC_TILE; i += 256) sT[j * GPCC_DIAG_LD + i] = sT[i * GPCC_DIAG_LD + j] * inv;
+        for (int i = j + 1 + ty; i < GPCC_TILE; i += 16) {
+            const double aij = sT[i * GPCC_DIAG_LD + j] * invd;
+            for (int cc = j + 1 + tx; cc <= i; cc += 16) sT[i * GPCC_DIAG_LD + cc] -= aij * sT[cc * GPCC_DIAG_LD + j];
+        }
+    }
+    __syncthreads();
+    // now: upper triangle row j = column j of L (below the diagonal), sD = diag(L)
+    double part = (tid < GPCC_TILE) ? log(sD[tid]) : 0.0;
+    sr[tid] = part;
+    // ---- X = inv(L): forward substitution on the identity, X lives in the dead lower triangle
+    for (int i = ty; i < GPCC_TILE; i += 16)
+        for (int cc = tx; cc <= i; cc += 16) sT[i * GPCC_DIAG_LD + cc] = (i == cc) ? 1.0 : 0.0;
+    for (int j = 0; j < GPCC_TILE; ++j) {
+        __syncthreads();
+        const double ij = sI[j];
+        for (int i = j + 1 + ty; i < GPCC_TILE; i += 16) {
+            const double lij = sT[j * GPCC_DIAG_LD + i] * ij;  // L_ij / L_jj
+            for (int cc = tx; cc <= j; cc += 16) sT[i * GPCC_DIAG_LD + cc] -= lij * sT[j * GPCC_DIAG_LD + cc];
+        }
+    }
+    __syncthreads();
+    for (int i = ty; i < GPCC_TILE; i += 16) {
+        const double ii = sI[i];
+        for (int cc = tx; cc <= i; cc += 16) sT[i * GPCC_DIAG_LD + cc] *= ii;
+    }
+    __syncthreads();
+    // ---- w_k = X z_k
+    double wi = 0.0;
+    if (tid < GPCC_TILE) {
+        for (int cc = 0; cc <= tid; ++cc) wi += sT[tid * GPCC_DIAG_LD + cc] * sz[cc];
+        c.w[(long)slot * c.Np + k * GPCC_TILE + tid] = wi;
+    }
+    // reductions: sr holds log L_ii; reduce both sums by thread 0 in a fixed order (deterministic)
+    __syncthreads();
+    if (tid < GPCC_TILE) sz[tid] = wi * wi;
+    __syncthreads();
+    if (tid == 0) {
+        double ld = 0.0, qd = 0.0;
+        for (int i = 0; i < GPCC_TILE; ++i) { ld += sr[i]; qd += sz[i]; }
+        ld += c.logdet[slot];
+        qd += c.quad[slot];
+        c.logdet[slot] = ld;
+        c.quad[slot] = qd;
+        const int bad = *sbad;
+        if (bad) c.info[slot] = k * GPCC_TILE + bad;
+        if (last) {
+            const double log2pi = 1.8378770664093454835606594728112;
+            g.out_loglik[g.first + m] = bad ? __builtin_nan("") : (-((double)c.N * log2pi + 2.0 * ld) / 2.0 - qd / 2.0);
+            g.out_info[g.first + m] = bad ? (k * GPCC_TILE + bad) : 0;
+        }
+    }
+    // ---- write inv(L_kk) (B operand of the panel solve) and L_kk, both in tile layout
+    double *Linv = c.linv + (long)slot * GPCC_TILE_ELEMS;
+    for (int e = tid; e < GPCC_TILE_ELEMS; e += 256) {
+        const int ch = e >> 11, rem = e & 2047, r = rem >> 4, col = ch * 16 + (rem & 15);
+        Linv[e] = (col <= r) ? sT[r * GPCC_DIAG_LD + col] : 0.0;
+        T[e] = (col < r) ? sT[col * GPCC_DIAG_LD + r] : ((col == r) ? sD[r] : 0.0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// dense exports (tests, prediction): tiles of one slot -> column-major N x N
+// ------------------------------------------------------------------------------------------
+__global__ void gpcc_export_dense(GpccCtx c, int slot, double *out, int symmetric)
+{
+    const long n = c.N;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n) return;
+    const int r = (int)(idx % n), col = (int)(idx / n);
+    const double *tiles = c.tiles + (long)slot * c.slot_stride;
+    double v;
+    if (r >= col)
+        v = tiles[gpcc_tile_off(r >> 7, col >> 7) + gpcc_elem_off(r & 127, col & 127)];
+    else
+        v = symmetric ? tiles[gpcc_tile_off(col >> 7, r >> 7) + gpcc_elem_off(col & 127, r & 127)] : 0.0;
+    out[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// delayedCovariance(kernel, scale, delays, rho, x, y), rectangular, column-major output
+// (src/delayedCovariance.jl:1-35).  xu/yu arrive already shifted (x - delays[band]).
+// ------------------------------------------------------------------------------------------
+template <int KID>
+__global__ void gpcc_covariance_kernel(long nx, long ny, const double *xu, const double *xs, const double *yu,
+                                       const double *ys, double rho, double *out)
+{
+#pragma clang fp contract(off)
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nx * ny) return;
+    const long r = idx % nx, col = idx / nx;
+    out[idx] = (xs[r] * ys[col]) * gpcc_kernel_eval<KID>(xu[r], yu[col], rho);
+}
+
+// ------------------------------------------------------------------------------------------
+// getprobabilities (src/getprobabilities.jl:10-20): exp(joint - logsumexp(joint)), one block.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void gpcc_probabilities_kernel(int G, const double *ll, const double *lp,
+                                                                  double *out)
+{
+    __shared__ double red[1024];
+    const int tid = threadIdx.x;
+    double mx = -INFINITY;
+    for (int i = tid; i < G; i += 1024) {
+        const double j = ll[i] + (lp ? lp[i] : 1.0);  // getprobabilities.jl:3: log-prior of ones
+        mx = fmax(mx, j);
+    }
+    red[tid] = mx;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = fmax(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    mx = red[0];
+    __syncthreads();
+    double sum = 0.0;
+    for (int i = tid; i < G; i += 1024) sum += exp(ll[i] + (lp ? lp[i] : 1.0) - mx);
+    red[tid] = sum;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const double lse = mx + log(red[0]);
+    for (int i = tid; i < G; i += 1024) out[i] = exp(ll[i] + (lp ? lp[i] : 1.0) - lse);
+}
+
+// ------------------------------------------------------------------------------------------
+// self-test: f64 MFMA fragment maps with asymmetric integer data, and a rate probe.
+// ------------------------------------------------------------------------------------------
+__global__ void gpcc_selftest_map(const double *A /*16x4 row-major*/, const double *B /*4x16 row-major*/,
+                                  double *D /*16x16 row-major*/)
+{
+    const int lane = threadIdx.x & 63, lr = lane & 15, q = lane >> 4;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[lr * 4 + q], B[q * 16 + lr], acc, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) D[(q + 4 * r) * 16 + lr] = acc[r];
+}
+
+__global__ __launch_bounds__(256) void gpcc_selftest_rate(double *sink, int iters)
+{
+    d4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+    const double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a3, 0, 0, 0);
+    }
+    d4 s = a0 + a1 + a2 + a3;
+    if (s[0] + s[1] + s[2] + s[3] == 12345.678) sink[0] = s[0];
+}

@@ -1,0 +1,126 @@
+/*
+ * gpcc_hip.h -- C ABI of libgpcc_hip.so: the MI355X (gfx950) implementation of GPCC.jl's
+ * marginal-log-likelihood hot path.
+ *
+ * The reference (pure Julia, /root/reference) has no FFI / plugin interface of its own
+ * (SURVEY.md section 8(b)); this header IS the boundary a maintainer binds with `ccall`
+ * (INTEGRATION.md shows the Julia shim) and the build's own host layer binds with ctypes
+ * (gpcc.jl_amd/_capi.py).  Each entry point cites the reference code whose body it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; host pointers unless the name ends in _device.
+ *   - every function returns int: 0 ok, <0 error (message via gpcc_last_error); never throws.
+ *   - per-item status in info[] follows LAPACK potrf: 0 ok; >0 = order of the first
+ *     non-positive pivot (the reference's PosDefException, swallowed by safewrapper at
+ *     src/gpccfixdelay_marginaliseb.jl:153), loglik = NaN; -1 = some alpha <= 0 (the @assert at
+ *     src/delayedCovariance.jl:3); -2 = rho <= 0 (error() at src/delayedCovariance.jl:5-7).
+ *   - ragged light curves are passed flattened in band order, user order inside a band
+ *     (Y = reduce(vcat, yarray), src/gpccfixdelay_marginaliseb.jl:85).
+ *   - per-evaluation parameter blocks are ROW-major M x L (Julia passes an L x M Matrix).
+ *   - no callbacks, no retained caller pointers, all device memory owned by the handle;
+ *     one handle per thread/process; several handles (and processes) may share a GPU.
+ *   - there is NO CPU fallback: without a HIP device every compute entry returns an error.
+ */
+#ifndef GPCC_HIP_H
+#define GPCC_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gpcc_handle_s *gpcc_handle_t;
+
+/* kernel ids: src/util.jl:15-23 (OU), :28 (rbf), :32-40 (matern32), :44-52 (matern52).
+ * Any other Julia callable stays on the pure-Julia path. */
+enum { GPCC_KERNEL_OU = 0, GPCC_KERNEL_RBF = 1, GPCC_KERNEL_MATERN32 = 2, GPCC_KERNEL_MATERN52 = 3 };
+enum { GPCC_PRECISION_FP64 = 0, GPCC_PRECISION_FP32 = 1 };
+enum { GPCC_MAX_BANDS = 8 };
+
+enum {
+    GPCC_OK = 0,
+    GPCC_ERR_ARGUMENT = -1,      /* bad sizes / ids / NULL pointers */
+    GPCC_ERR_HIP = -2,           /* a HIP runtime call failed (no device, OOM, launch failure) */
+    GPCC_ERR_UNSUPPORTED = -3,   /* valid request this build does not implement yet */
+    GPCC_ERR_STATE = -4
+};
+
+int gpcc_version(void);
+
+/* Last error text of a handle; handle == NULL gives the calling thread's last
+ * handle-less error (gpcc_create / gpcc_covariance / gpcc_probabilities). */
+const char *gpcc_last_error(gpcc_handle_t handle);
+
+/* Replaces the per-call precompute of gpccfixdelay (src/gpccfixdelay_marginaliseb.jl:85-98;
+ * src/gpccfixdelay.jl:85-96 when marginalise_b == 0): uploads t, sigma^2, Y - bbar once and keeps
+ * mu_b[l] = mean(y_l), Sigma_b[l] = 100 var(y_l) (n-1).  Nl[l] >= 1 (>= 2 when marginalise_b). */
+int gpcc_create(gpcc_handle_t *handle, int L, const int *Nl, const double *t, const double *y,
+                const double *sigma, int kernel_id, int marginalise_b, int precision, int device_id);
+int gpcc_destroy(gpcc_handle_t handle);
+
+/* Tunables, before the first evaluation: "streams" (concurrent groups, default 2),
+ * "slots_per_stream" (matrices resident per group, default 64), "lds_dma" (0/1). */
+int gpcc_set_option(gpcc_handle_t handle, const char *key, long value);
+long gpcc_get_option(gpcc_handle_t handle, const char *key);
+
+/* mu_b[L], Sigma_b[L], resid[N] as precomputed at create (any pointer may be NULL). */
+int gpcc_get_constants(gpcc_handle_t handle, double *mean_b, double *Sigma_b, double *resid);
+
+/* THE HOT PATH.  objective(alpha, rho) of src/gpccfixdelay_marginaliseb.jl:133-141
+ * (src/gpccfixdelay.jl:131-139 when marginalise_b == 0) for M independent (tau, alpha, rho):
+ *   K = delayedCovariance(kernel, alpha, tau, rho, tarray) + Sobs + B ; logpdf(MvNormal(bbar, K), Y).
+ * M = 1 serves the closure call site (:145-153, :209, :211); large M serves the delay-grid sweep
+ * (README.md:172-174, :202-206, :231).  Blocking; caller-allocated outputs. */
+int gpcc_loglik_batch(gpcc_handle_t handle, int M, const double *delays, const double *alpha,
+                      const double *rho, double *loglik, int *info);
+
+/* Same with DEVICE pointers, enqueued behind `stream` (a hipStream_t, NULL = default stream) and
+ * joined back into it: asynchronous, outputs valid once `stream` has drained. */
+int gpcc_loglik_batch_device(gpcc_handle_t handle, int M, const double *d_delays,
+                             const double *d_alpha, const double *d_rho, double *d_loglik,
+                             int *d_info, void *stream);
+
+/* Dense K = delayedCovariance + Sobs + B of one (tau, alpha, rho), column-major N x N
+ * (src/gpccfixdelay_marginaliseb.jl:135, :237-241) -- for prediction and tests. */
+int gpcc_model_matrix(gpcc_handle_t handle, const double *delays, const double *alpha, double rho,
+                      double *K_out);
+
+/* Lower Cholesky factor of that K (PDMat's cholesky at marginaliseb.jl:139), column-major N x N,
+ * strict upper triangle zero; *info as above. */
+int gpcc_factor_dense(gpcc_handle_t handle, const double *delays, const double *alpha, double rho,
+                      double *L_out, int *info);
+
+/* delayedCovariance(kernel, scale, delays, rho, x, y) of src/delayedCovariance.jl:1-35 (pass
+ * y == x, Ny == Nx for the 5-argument form, :38).  out is column-major (sum Nx) x (sum Ny).
+ * Returns GPCC_ERR_ARGUMENT with the reference's message for scale <= 0 / rho <= 0. */
+int gpcc_covariance(int kernel_id, int L, const double *scale, const double *delays, double rho,
+                    const int *Nx, const double *x, const int *Ny, const double *y, double *out,
+                    int device_id);
+
+/* getprobabilities(loglikel[, logpriorpdfvalues]) of src/getprobabilities.jl:1-20;
+ * logprior == NULL is the 1-argument form (log-prior of ones, :3). */
+int gpcc_probabilities(int G, const double *loglik, const double *logprior, double *out,
+                       int device_id);
+int gpcc_probabilities_device(int G, const double *d_loglik, const double *d_logprior,
+                              double *d_out, void *stream);
+
+/* Per-kernel HIP-event timing (bench.py's roofline leg).  While enabled every launch is
+ * bracketed by events on its own stream and groups run on ONE stream. */
+enum {
+    GPCC_PROF_ASSEMBLE = 0,     /* gpcc_assemble_tiles     -- HBM-bound */
+    GPCC_PROF_PANEL_UPDATE = 1, /* gpcc_panel_update       -- fp64 MFMA, dominant */
+    GPCC_PROF_DIAG = 2,         /* gpcc_diag_factor */
+    GPCC_PROF_TRSM = 3,         /* gpcc_panel_trsm         -- fp64 MFMA */
+    GPCC_PROF_COUNT = 4
+};
+int gpcc_profile_enable(gpcc_handle_t handle, int on);
+int gpcc_profile_reset(gpcc_handle_t handle);
+int gpcc_profile_get(gpcc_handle_t handle, int which, long *launches, double *total_ms);
+
+/* On-device self-test of the f64 MFMA fragment maps and a timing probe of the fp64 MFMA rate:
+ * returns 0 when the maps are as the kernels assume; *tflops (may be NULL) = measured rate. */
+int gpcc_selftest(int device_id, double *mfma_f64_tflops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

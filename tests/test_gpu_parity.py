@@ -1,0 +1,173 @@
+"""GPU parity tests: the HIP path, called through the C ABI (gpcc_amd -> ctypes -> libgpcc_hip.so),
+against the CPU oracle and the committed golden fixtures.
+
+Tolerances: log-likelihood 1e-8 relative here (BASELINE north_star demands 1e-6 in fp64); matrix
+elements 1e-13 relative (exp() of ocml vs libm differ in the last bits); bit-exactness is not
+expected of floating-point work."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LL_RTOL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def gp():
+    import gpcc_amd
+    return gpcc_amd
+
+
+def _rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b)) / np.abs(np.asarray(b)))
+
+
+def test_selftest_mfma_map_and_rate(gp):
+    tf = gp.selftest(0)
+    print("fp64 MFMA rate: %.1f TFLOP/s" % tf)
+    assert tf > 5.0
+
+
+def test_covariance_golden(gp, golden):
+    for c in golden["covariances"]:
+        Kxy = gp.delayedCovariance(c["kernel"], c["scale"], c["delays"], c["rho"], c["x"], c["y"])
+        Kxx = gp.delayedCovariance(gp.KERNELS[c["kernel"]], c["scale"], c["delays"], c["rho"], c["x"])
+        np.testing.assert_allclose(Kxy, np.array(c["Kxy"]), rtol=1e-13, atol=1e-300)
+        np.testing.assert_allclose(Kxx, np.array(c["Kxx"]), rtol=1e-13, atol=1e-300)
+
+
+def test_covariance_errors(gp):
+    x = [[0.0, 1.0], [0.5]]
+    with pytest.raises(AssertionError):
+        gp.delayedCovariance(gp.OU, [1.0, 0.0], [0.0, 0.0], 1.0, x)
+    with pytest.raises(ValueError):
+        gp.delayedCovariance(gp.OU, [1.0, 1.0], [0.0, 0.0], -1.0, x)
+    with pytest.raises(TypeError):
+        gp.delayedCovariance(lambda a, b: 0.0, [1.0, 1.0], [0.0, 0.0], 1.0, x)
+
+
+def test_probabilities_golden(gp, golden):
+    p = golden["probabilities"]
+    np.testing.assert_allclose(gp.getprobabilities(p["loglik"]), p["p_flat"], rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(gp.getprobabilities(p["loglik"], p["logprior"]), p["p_prior"], rtol=1e-12,
+                               atol=1e-300)
+    ll = np.random.default_rng(0).standard_normal((5, 7)) * 40 - 2000
+    q = gp.getprobabilities(ll)
+    assert q.shape == ll.shape and abs(q.sum() - 1) < 1e-12
+
+
+@pytest.mark.parametrize("lds_dma", [0, 1])
+def test_loglik_golden_cases(gp, golden, lds_dma):
+    worst = 0.0
+    for c in golden["cases"]:
+        with gp.Objective(c["t"], c["y"], c["sigma"], c["kernel"], marginalise_b=c["marginalise_b"],
+                          lds_dma=lds_dma, slots_per_stream=4) as obj:
+            ll, info = obj.loglik_batch([c["delays"]], [c["alpha"]], [c["rho"]])
+        assert info[0] == 0
+        worst = max(worst, abs(ll[0] - c["loglik"]) / abs(c["loglik"]))
+    print("worst relative error vs golden: %.3e" % worst)
+    assert worst <= LL_RTOL
+
+
+def test_model_matrix_and_factor_vs_oracle(gp, oracle):
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([171, 171, 171], seed=3)   # N = 513: ragged last tile
+    delays, alpha, rho = [0.0, 1.3, 4.1], [0.8, 1.1, 1.7], 2.9
+    for kname in ("OU", "rbf", "matern32", "matern52"):
+        for mb in (True, False):
+            with gp.Objective(t, y, s, kname, marginalise_b=mb, slots_per_stream=2) as obj:
+                K = obj.model_matrix(delays, alpha, rho)
+                Kref, rref = oracle.model_matrix(kname, t, y, s, delays, alpha, rho, mb)
+                np.testing.assert_allclose(K, Kref, rtol=1e-13, atol=1e-300)
+                assert np.array_equal(K, K.T)
+                _, _, r = obj.constants()
+                np.testing.assert_allclose(r, rref, rtol=1e-14, atol=1e-14)
+                if kname == "matern32":
+                    Lf, info = obj.factor(delays, alpha, rho)
+                    Lref, iref = oracle.potrf_lower(Kref)
+                    assert info == 0 and iref == 0
+                    assert np.max(np.abs(Lf - Lref)) <= 1e-9 * np.max(np.abs(Lref))
+                    assert np.array_equal(Lf, np.tril(Lf))
+
+
+@pytest.mark.parametrize("kname", ["OU", "rbf", "matern32", "matern52"])
+def test_loglik_medium_vs_oracle_grouped(gp, oracle, kname):
+    """N = 2 x 512, 22 evaluations with different (tau, alpha, rho) through groups of 4 on 2 streams."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([512, 512], seed=2, gap_band=1)
+    rng = np.random.default_rng(7)
+    M = 22
+    delays = np.stack([np.zeros(M), rng.random(M) * 20], 1)
+    alpha = 0.5 + rng.random((M, 2)) * 2
+    rho = 1.0 + rng.random(M) * 5
+    ref, rinfo = oracle.loglik_batch(kname, t, y, s, delays, alpha, rho, True, nthreads=8)
+    for dma in (0, 1):
+        with gp.Objective(t, y, s, kname, slots_per_stream=4, streams=2, lds_dma=dma) as obj:
+            ll, info = obj.loglik_batch(delays, alpha, rho)
+            ok = rinfo == 0
+            assert np.array_equal(info == 0, ok)
+            assert _rel(ll[ok], ref[ok]) <= LL_RTOL
+            # a second call reuses the slots
+            ll2, _ = obj.loglik_batch(delays[:5], alpha[:5], rho[:5])
+            assert np.array_equal(ll2[ok[:5]], ll[:5][ok[:5]])
+            # the closure form
+            if ok[0]:
+                assert obj(alpha[0], rho[0], delays[0]) == ll[0]
+
+
+def test_status_codes(gp, golden):
+    c = golden["nonpd"]
+    with gp.Objective(c["t"], c["y"], c["sigma"], c["kernel"], marginalise_b=c["marginalise_b"]) as obj:
+        ll, info = obj.loglik_batch([c["delays"], c["delays"], c["delays"], [0.0, 1.0]],
+                                    [c["alpha"], [1.0, -1.0], c["alpha"], c["alpha"]],
+                                    [c["rho"], 1.0, 0.0, 2.0])
+        assert info[0] > 0 and np.isnan(ll[0])          # PosDefException
+        assert info[1] == -1 and np.isnan(ll[1])        # alpha <= 0
+        assert info[2] == -2 and np.isnan(ll[2])        # rho <= 0
+        with pytest.raises(gp.PosDefException):
+            obj(c["alpha"], c["rho"], c["delays"])
+        with pytest.raises(AssertionError):
+            obj([1.0, -1.0], 1.0, c["delays"])
+        with pytest.raises(ValueError):
+            obj(c["alpha"], 0.0, c["delays"])
+        ll, info = obj.loglik_batch(np.zeros((0, 2)), np.zeros((0, 2)), np.zeros(0))   # empty batch
+        assert len(ll) == 0
+
+
+def test_fixed_b_variant_and_single_band(gp, oracle):
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([300], seed=5)
+    with gp.Objective(t, y, s, gp.matern52, marginalise_b=False) as obj:
+        ll, info = obj.loglik_batch([[0.0], [3.3], [-8.0]], [[1.2]] * 3, [2.2] * 3)
+        ref, _ = oracle.loglik_batch("matern52", t, y, s, [[0.0]], [[1.2]], [2.2], False)
+    assert (info == 0).all() and _rel(ll, np.repeat(ref, 3)) <= LL_RTOL
+    assert np.ptp(ll) <= 1e-10 * abs(ll[0])     # single band: independent of the delay
+
+
+def test_full_size_properties_and_oracle(gp, oracle):
+    """BASELINE size (2 x 2048, Matern-3/2, fp64): size-independent properties on the GPU, plus two
+    evaluations against the oracle."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([2048, 2048], seed=1)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    grid = np.linspace(0.0, 20.0, 12)
+    delays = np.stack([np.zeros_like(grid), grid], 1)
+    M = len(grid)
+    with gp.Objective(t, y, s, gp.matern32) as obj:
+        ll, info = obj.loglik_batch(delays, np.tile(alpha, (M, 1)), np.full(M, rho))
+        assert (info == 0).all()
+        # adding a constant to every delay leaves K unchanged
+        ll_s, _ = obj.loglik_batch(delays + 3.5, np.tile(alpha, (M, 1)), np.full(M, rho))
+        assert _rel(ll_s, ll) <= 1e-9
+        ref, rinfo = oracle.loglik_batch("matern32", t, y, s, delays[[1, 7]], np.tile(alpha, (2, 1)),
+                                         np.full(2, rho), True, nthreads=2)
+        assert (rinfo == 0).all() and _rel(ll[[1, 7]], ref) <= LL_RTOL
+    # permuting observations inside a band leaves the log-likelihood unchanged
+    rng = np.random.default_rng(9)
+    p0, p1 = rng.permutation(2048), rng.permutation(2048)
+    tp, yp, sp = [t[0][p0], t[1][p1]], [y[0][p0], y[1][p1]], [s[0][p0], s[1][p1]]
+    with gp.Objective(tp, yp, sp, gp.matern32) as obj:
+        ll_p, _ = obj.loglik_batch(delays[:3], np.tile(alpha, (3, 1)), np.full(3, rho))
+    assert _rel(ll_p, ll[:3]) <= 1e-9
+    p = gp.getprobabilities(ll)
+    assert abs(p.sum() - 1) < 1e-12

@@ -1,0 +1,75 @@
+"""CPU-side checks of the product package: the C-ABI library loads and exports every symbol of
+include/gpcc_hip.h, fails loudly without a GPU (no fallback), host logic of the sharding."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from gpcc_amd import _capi
+    from gpcc_amd import build
+    build.build()
+    return _capi.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from gpcc_amd import _capi
+    header = open(os.path.join(ROOT, "include", "gpcc_hip.h")).read()
+    declared = set(re.findall(r"\b(gpcc_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no prototypes found"
+    assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.gpcc_version() >= 100
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import gpcc_amd
+    with pytest.raises(gpcc_amd.GpccError) as ei:
+        gpcc_amd.getprobabilities([0.0, 1.0])
+    assert "no HIP device" in str(ei.value)
+    with pytest.raises(gpcc_amd.GpccError):
+        gpcc_amd.Objective([[0.0, 1.0]], [[1.0, 2.0]], [[0.1, 0.1]], gpcc_amd.OU)
+    with pytest.raises(gpcc_amd.GpccError):
+        gpcc_amd.delayedCovariance(gpcc_amd.OU, [1.0], [0.0], 1.0, [[0.0, 1.0]])
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "gpcc.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.lower(), os.path.join(dirpath, f)
+
+
+def test_shard_bounds_partition():
+    from gpcc_amd import shard_bounds
+    for G in (0, 1, 7, 256, 1024, 65536):
+        for world in (1, 2, 3, 8):
+            covered = []
+            for r in range(world):
+                lo, hi = shard_bounds(G, world, r)
+                covered.extend(range(lo, hi))
+                assert hi - lo in (G // world, G // world + 1)
+            assert covered == list(range(G))
+
+
+def test_synthetic_recipe():
+    from gpcc_amd import synthetic
+    t, y, s, td = synthetic.simulate_lightcurves([300, 200, 100], seed=4, gap_band=1)
+    assert [len(a) for a in t] == [300, 200, 100] and td == [0.0, 2.0, 4.0]
+    assert not np.all(np.diff(t[0]) > 0)            # unsorted, like the reference
+    assert abs(np.mean(y[0]) - 6) < 1.5 and abs(np.mean(y[2]) - 25) < 4
+    gap = t[1]
+    assert ((gap <= 0.4 * 200 / 3) | (gap >= 0.6 * 200 / 3)).all()
+    t2, y2, _, _ = synthetic.simulate_lightcurves([300, 200, 100], seed=4, gap_band=1)
+    assert all(np.array_equal(a, b) for a, b in zip(t, t2)) and all(np.array_equal(a, b) for a, b in zip(y, y2))
