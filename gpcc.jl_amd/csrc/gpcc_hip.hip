@@ -27,7 +27,7 @@ struct gpcc_handle_s {
     double *d_t = nullptr, *d_sig2 = nullptr, *d_resid = nullptr;
     int *d_band = nullptr;
     // options
-    int streams = 2, slots_per_stream = 64, lds_dma = 0;
+    int streams = 1, slots_per_stream = 256, lds_dma = 1;
     // workspace
     bool ws_ready = false;
     int ws_streams = 0, ws_slots = 0;
@@ -116,6 +116,12 @@ extern "C" int gpcc_create(gpcc_handle_t *out, int L, const int *Nl, const doubl
     h->N = (int)N;
     h->nt = (int)((N + GPCC_TILE - 1) / GPCC_TILE);
     h->Np = h->nt * GPCC_TILE;
+    {   // default group size: 256 evaluations resident (one per CU in the diagonal step), capped at 64 GiB
+        const double per_slot = ((double)h->nt * (h->nt + 1) / 2 + 1) * GPCC_TILE_ELEMS * 8.0 + 16.0 * h->Np;
+        long cap = (long)(64.0 * 1024 * 1024 * 1024 / per_slot);
+        if (cap < 8) cap = 8;
+        if (h->slots_per_stream > cap) h->slots_per_stream = (int)(cap / 8 * 8);
+    }
     h->kernel_id = kernel_id;
     h->mb = marginalise_b ? 1 : 0;
     h->precision = precision;
@@ -253,10 +259,8 @@ static int ensure_workspace(gpcc_handle_t h)
     }
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_diag_factor, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   GPCC_DIAG_LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_gemm_nt<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_gemm_nt<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_gemm_nt<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_gemm_nt<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
     h->ws_streams = h->streams;
     h->ws_slots = h->slots_per_stream;
     h->ws_ready = true;
@@ -308,9 +312,7 @@ static int enqueue_group(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, 
     for (int k = 0; k < c.nt; ++k) {
         if (k > 0) {
             ProfScope p(h, GPCC_PROF_PANEL_UPDATE, s);
-            const int grid = cnt8 * (c.nt - k);
-            if (h->lds_dma) gpcc_gemm_nt<false, true><<<grid, 256, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
-            else gpcc_gemm_nt<false, false><<<grid, 256, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
+            gpcc_panel_update<<<cnt8 * (c.nt - k), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
         }
         {
             ProfScope p(h, GPCC_PROF_DIAG, s);
@@ -318,9 +320,7 @@ static int enqueue_group(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, 
         }
         if (k < c.nt - 1) {
             ProfScope p(h, GPCC_PROF_TRSM, s);
-            const int grid = cnt8 * (c.nt - k - 1);
-            if (h->lds_dma) gpcc_gemm_nt<true, true><<<grid, 256, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
-            else gpcc_gemm_nt<true, false><<<grid, 256, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
+            gpcc_panel_trsm<<<cnt8 * (c.nt - k - 1), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
         }
     }
     hipError_t e = hipGetLastError();

@@ -4,9 +4,11 @@
 // lower triangle of its padded Np x Np matrix (Np = nt*128) as nt(nt+1)/2 TILES of 128x128
 // doubles; tile (I,J), J<=I, sits at ((I(I+1)/2)+J)*16384.  Inside a tile the 128 columns are
 // cut into 8 CHUNKS of 16; a chunk is 128 rows x 16 columns stored row-major = one contiguous
-// 16 KiB block that is copied 1:1 into LDS (register staging or LDS-DMA) and from which the
-// f64 MFMA fragments are read with two ds_read_b128 per fragment.  A row of tiles (I,0..I) is
-// contiguous, so both operand streams of the left-looking update are purely sequential reads.
+// 16 KiB block that LDS-DMA copies 1:1 into LDS and from which the f64 MFMA fragments are read
+// with two ds_read_b128 per fragment.  Inside a row the eight 16-byte slots are XOR-swizzled
+// (gpcc_sw) so that those reads are bank-conflict-free; the swizzle lives in the HBM layout, so the
+// DMA stays a linear copy.  A row of tiles (I,0..I) is contiguous, so both operand streams of the
+// left-looking update are purely sequential reads.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -19,6 +21,7 @@
 #define GPCC_DIAG_LD 129
 #define GPCC_DIAG_LDS_BYTES ((GPCC_TILE * GPCC_DIAG_LD + 3 * GPCC_TILE + 256) * 8 + 16)
 #define GPCC_GEMM_LDS_BYTES (2 * 2 * GPCC_CHUNK * 8)
+#define GPCC_GEMM_THREADS 512
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -51,9 +54,18 @@ __device__ __forceinline__ long gpcc_tile_off(int I, int J)
 {
     return ((long)I * (I + 1) / 2 + J) * GPCC_TILE_ELEMS;
 }
+// Slot swizzle of row r (depends on row bits 1..3).  ds_read_b128 is served in 16-lane groups
+// {q even, rows 0-3,12-15 | q odd, rows 4-11} (and the mirrored one); g maps the row pairs
+// {0,1,6,7} -> {0,2,4,6} and {2,3,4,5} -> {1,3,5,7}, both sets closed under the xor with the slot
+// bases 2q, so the 16 lanes of a group hit 16 different 16-byte bank groups of the 256-byte LDS row.
+__device__ __forceinline__ int gpcc_sw(int r)
+{
+    const int p = (r >> 1) & 7;
+    return (((p >> 2) & 1) << 2) | ((p & 1) << 1) | (((p >> 2) ^ (p >> 1)) & 1);
+}
 __device__ __forceinline__ int gpcc_elem_off(int r, int col)
 {
-    return (col >> 4) * GPCC_CHUNK + r * GPCC_KC + (col & 15);
+    return (col >> 4) * GPCC_CHUNK + r * GPCC_KC + (((((col & 15) >> 1) ^ gpcc_sw(r)) << 1) | (col & 1));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
 #pragma unroll 4
     for (int it = 0; it < 32; ++it) {
         const int e = tid + 256 * it;  // 16-byte piece index inside the tile
-        const int ch = e >> 10, rem = e & 1023, r = rem >> 3, col = ch * 16 + (rem & 7) * 2;
+        const int ch = e >> 10, rem = e & 1023, r = rem >> 3, col = ch * 16 + (((rem & 7) ^ gpcc_sw(r)) << 1);
         d2 v;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -155,165 +167,209 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
 }
 
 // ------------------------------------------------------------------------------------------
-// gpcc_gemm_nt<TRSM, DMA>: the fp64 MFMA kernel.  One workgroup (4 waves, each a 64x64
-// quadrant = 4x4 v_mfma_f64_16x16x4_f64 accumulators) produces one 128x128 tile.
-//   TRSM == false (panel update, step k, tile I>=k):  T(I,k) -= sum_{j<k} L(I,j) L(k,j)^T
-//       K-loop over the 8k chunks of the two contiguous tile rows I and k.
-//   TRSM == true  (panel solve, step k, tile I>k):     L(I,k) = T(I,k) inv(L_kk)^T  and
-//       z_I -= L(I,k) w_k (the forward substitution of logpdf's whitening, fused).
-// Together these replace LAPACK dpotrf's dsyrk/dgemm/dtrsm inside cholesky(K)
-// (reached from marginaliseb.jl:139 via Distributions/PDMats).
-// Operands are staged through a 2-deep LDS ring (64 KiB), by registers or by LDS-DMA.
-// Blocks of one evaluation share blockIdx % 8, i.e. an XCD and its L2, because they all
-// stream the same tile row k.
+// The fp64 MFMA kernels.  Measured on MI355X (tools/microbench.hip): v_mfma_f64_16x16x4_f64
+// issues every 64 cycles per SIMD (77.6 TFLOP/s chip-wide) only when at least TWO waves of that
+// SIMD have MFMAs to issue -- one wave alone gets one per ~139 cycles whatever its number of
+// independent accumulators -- and VALU DFMA shares the same 78 TFLOP/s.  Hence: 8-wave workgroups,
+// a 32x64 (panel update) or 16x128 (panel solve) sub-tile per wave = 8 accumulators = 64 VGPRs,
+// <= 128 VGPRs in all, two workgroups per CU = FOUR waves per SIMD, so barriers and LDS-DMA waits
+// of one wave are covered by three others.
+// Operands go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, the
+// 16 KiB chunk lands as a linear copy) into a 2-deep ring: 2 x (A 16 KiB + B 16 KiB) = 64 KiB.
 // ------------------------------------------------------------------------------------------
-template <bool TRSM, bool DMA>
-__global__ __launch_bounds__(256, 2) void gpcc_gemm_nt(GpccCtx c, GpccGroup g, int k)
+__device__ __forceinline__ void gpcc_dma_chunk(const double *gA, const double *gB, double *stage, int wave, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int piece = wave * 2 + i;  // 16 pieces of 1 KiB per 16 KiB chunk, 8 waves x 2
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gA + piece * 128 + lane * 2),
+                                         (__attribute__((address_space(3))) void *)(stage + piece * 128), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gB + piece * 128 + lane * 2),
+                                         (__attribute__((address_space(3))) void *)(stage + GPCC_CHUNK + piece * 128), 16, 0,
+                                         0);
+    }
+}
+
+// One fragment = the 4 consecutive k (4q..4q+3) of one row: two swizzled 16-byte slots.
+__device__ __forceinline__ void gpcc_load_frag(const double *chunk, int row, int q, int sw, d2 &lo, d2 &hi)
+{
+    const double *p = chunk + row * GPCC_KC;
+    lo = *(const d2 *)(p + (((2 * q) ^ sw) << 1));
+    hi = *(const d2 *)(p + (((2 * q + 1) ^ sw) << 1));
+}
+
+// ------------------------------------------------------------------------------------------
+// gpcc_panel_update (step k, tile I >= k):  T(I,k) -= sum_{j<k} L(I,j) L(k,j)^T
+// = LAPACK dpotrf's dsyrk/dgemm (reached from cholesky(K), marginaliseb.jl:139), left-looking:
+// the K-loop runs over the 8k chunks of the two contiguous tile rows I and k, the accumulator
+// starts at -T(I,k) and is stored back negated (no read-modify-write).  The diagonal tile
+// (I == k, dsyrk) is computed in full like the others (4.5 % of the update flops are redundant).
+// Blocks of one evaluation share blockIdx % 8, i.e. (as dispatched) an XCD and its L2: they all
+// stream tile row k.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup g, int k)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, q = lane >> 4;
+    const int sw = gpcc_sw(lr);
 
-    const int per = TRSM ? (c.nt - k - 1) : (c.nt - k);
+    const int per = c.nt - k;
     const int x = blockIdx.x & 7, qq = blockIdx.x >> 3;
     const int m = (qq / per) * 8 + x;
     if (m >= g.cnt) return;
-    const int I = (TRSM ? k + 1 : k) + qq % per;
+    const int I = k + qq % per;
     const int slot = g.slot0 + m;
     if (c.info[slot] != 0) return;
 
     double *tiles = c.tiles + (long)slot * c.slot_stride;
-    const double *gA = tiles + (TRSM ? gpcc_tile_off(I, k) : gpcc_tile_off(I, 0));
-    const double *gB = TRSM ? (c.linv + (long)slot * GPCC_TILE_ELEMS) : (tiles + gpcc_tile_off(k, 0));
-    const int nch = TRSM ? 8 : 8 * k;
-
-    // f64 16x16x4 C/D map: col = lane&15, row = (lane>>4) + 4*reg  (checked by gpcc_selftest)
+    const double *gA = tiles + gpcc_tile_off(I, 0);
+    const double *gB = tiles + gpcc_tile_off(k, 0);
     double *T = tiles + gpcc_tile_off(I, k);
-    d4 acc[4][4];
-    if (TRSM) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-    } else {
-        // acc starts at -T(I,k): the epilogue is then a pure store of -acc (no read-modify-write)
-#pragma unroll
-        for (int fm = 0; fm < 4; ++fm)
-#pragma unroll
-            for (int fn = 0; fn < 4; ++fn)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[fm][fn][r] = -T[(wc * 4 + fn) * GPCC_CHUNK + (wr * 64 + fm * 16 + q + 4 * r) * GPCC_KC + lr];
-    }
+    const int nch = 8 * k;
 
-    d2 ra[4], rb[4];
-    auto gload = [&](int ch) {
-        const d2 *pa = (const d2 *)(gA + (long)ch * GPCC_CHUNK);
-        const d2 *pb = (const d2 *)(gB + (long)ch * GPCC_CHUNK);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { ra[i] = pa[tid + 256 * i]; rb[i] = pb[tid + 256 * i]; }
-    };
-    auto sstore = [&](int buf) {
-        d2 *sA = (d2 *)(smem + buf * 2 * GPCC_CHUNK);
-        d2 *sB = (d2 *)(smem + buf * 2 * GPCC_CHUNK + GPCC_CHUNK);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { sA[tid + 256 * i] = ra[i]; sB[tid + 256 * i] = rb[i]; }
-    };
-    auto dma = [&](int ch, int buf) {
-        // one wave-instruction moves 1 KiB: LDS destination = wave-uniform base + lane*16
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = wave * 4 + i;
-            const double *srcA = gA + (long)ch * GPCC_CHUNK + piece * 128 + lane * 2;
-            const double *srcB = gB + (long)ch * GPCC_CHUNK + piece * 128 + lane * 2;
-            double *dstA = smem + buf * 2 * GPCC_CHUNK + piece * 128;
-            double *dstB = dstA + GPCC_CHUNK;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)srcA,
-                                             (__attribute__((address_space(3))) void *)dstA, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)srcB,
-                                             (__attribute__((address_space(3))) void *)dstB, 16, 0, 0);
-        }
-    };
-    auto compute = [&](int buf) {
-        const double *sA = smem + buf * 2 * GPCC_CHUNK;
-        const double *sB = sA + GPCC_CHUNK;
-        d2 a[4][2], b[4][2];
-        // lane (lr, q) holds k = 4q..4q+3 of its row: the MFMA sums over q, the 4 steps over s
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const d2 *pa = (const d2 *)(sA + (wr * 64 + f * 16 + lr) * GPCC_KC + 4 * q);
-            const d2 *pb = (const d2 *)(sB + (wc * 64 + f * 16 + lr) * GPCC_KC + 4 * q);
-            a[f][0] = pa[0]; a[f][1] = pa[1];
-            b[f][0] = pb[0]; b[f][1] = pb[1];
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int fm = 0; fm < 4; ++fm)
-#pragma unroll
-                for (int fn = 0; fn < 4; ++fn)
-                    acc[fm][fn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[fm][s >> 1][s & 1], b[fn][s >> 1][s & 1],
-                                                                       acc[fm][fn], 0, 0, 0);
-    };
+    gpcc_dma_chunk(gA, gB, smem, wave, lane);
 
-    if (DMA) {
-        dma(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int ch = 0; ch < nch; ++ch) {
-            if (ch + 1 < nch) dma(ch + 1, (ch + 1) & 1);
-            compute(ch & 1);
+    // C/D map of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg (gpcc_selftest)
+    d4 acc[2][4];
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[fm][fn][r] = -T[gpcc_elem_off(wr * 32 + fm * 16 + q + 4 * r, wc * 64 + fn * 16 + lr)];
+
+    // per-lane LDS addresses: one base per 16-byte slot, fragments/stages are immediates from it
+    const double *pa0 = smem + (wr * 32 + lr) * GPCC_KC + (((2 * q) ^ sw) << 1);
+    const double *pa1 = smem + (wr * 32 + lr) * GPCC_KC + (((2 * q + 1) ^ sw) << 1);
+    const double *pb0 = smem + GPCC_CHUNK + (wc * 64 + lr) * GPCC_KC + (((2 * q) ^ sw) << 1);
+    const double *pb1 = smem + GPCC_CHUNK + (wc * 64 + lr) * GPCC_KC + (((2 * q + 1) ^ sw) << 1);
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ch2 = 0; ch2 < nch; ch2 += 2) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {  // stage st holds chunk ch2+st (nch = 8k is even)
+            const int ch = ch2 + st;
+            if (ch + 1 < nch)
+                gpcc_dma_chunk(gA + (long)(ch + 1) * GPCC_CHUNK, gB + (long)(ch + 1) * GPCC_CHUNK,
+                               smem + (st ^ 1) * 2 * GPCC_CHUNK, wave, lane);
+            const int so = st * 2 * GPCC_CHUNK;
+            d2 a[2][2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                a[f][0] = *(const d2 *)(pa0 + so + f * 16 * GPCC_KC);
+                a[f][1] = *(const d2 *)(pa1 + so + f * 16 * GPCC_KC);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {  // column fragments two at a time (register budget: 128)
+                d2 b[2][2];
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    b[f][0] = *(const d2 *)(pb0 + so + (2 * h + f) * 16 * GPCC_KC);
+                    b[f][1] = *(const d2 *)(pb1 + so + (2 * h + f) * 16 * GPCC_KC);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+                        for (int f = 0; f < 2; ++f)
+                            acc[fm][2 * h + f] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                                a[fm][s >> 1][s & 1], b[f][s >> 1][s & 1], acc[fm][2 * h + f], 0, 0, 0);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-    } else {
-        gload(0);
-        sstore(0);
-        __syncthreads();
-        for (int ch = 0; ch < nch; ++ch) {
-            if (ch + 1 < nch) gload(ch + 1);
-            compute(ch & 1);
-            if (ch + 1 < nch) sstore((ch + 1) & 1);
-            __syncthreads();
-        }
     }
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                T[gpcc_elem_off(wr * 32 + fm * 16 + q + 4 * r, wc * 64 + fn * 16 + lr)] = -acc[fm][fn][r];
+}
 
-    if (!TRSM) {
+// ------------------------------------------------------------------------------------------
+// gpcc_panel_trsm (step k, tile I > k):  L(I,k) = T(I,k) inv(L_kk)^T  (dtrsm as an MFMA product
+// with the explicit 128x128 inverse from gpcc_diag_factor; chunks of inv(L_kk) above the diagonal
+// are zero and skipped), fused with the forward substitution of logpdf's whitening:
+// z_I -= L(I,k) w_k.  Each wave owns 16 rows x all 128 columns, so the k-range of every column
+// fragment is the same for all waves (balanced) and the row sums need no cross-wave reduction.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 4) void gpcc_panel_trsm(GpccCtx c, GpccGroup g, int k)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, q = lane >> 4;
+    const int sw = gpcc_sw(lr);
+
+    const int per = c.nt - k - 1;
+    const int x = blockIdx.x & 7, qq = blockIdx.x >> 3;
+    const int m = (qq / per) * 8 + x;
+    if (m >= g.cnt) return;
+    const int I = k + 1 + qq % per;
+    const int slot = g.slot0 + m;
+    if (c.info[slot] != 0) return;
+
+    double *tiles = c.tiles + (long)slot * c.slot_stride;
+    double *T = tiles + gpcc_tile_off(I, k);
+    const double *gA = T;                                        // 8 chunks of T(I,k), overwritten at the end
+    const double *gB = c.linv + (long)slot * GPCC_TILE_ELEMS;    // inv(L_kk): rows = output column, k = j
+
+    gpcc_dma_chunk(gA, gB, smem, wave, lane);
+    d4 acc[8];
 #pragma unroll
-        for (int fm = 0; fm < 4; ++fm)
+    for (int fn = 0; fn < 8; ++fn) acc[fn] = (d4){0.0, 0.0, 0.0, 0.0};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 #pragma unroll
-            for (int fn = 0; fn < 4; ++fn)
+    for (int ch = 0; ch < 8; ++ch) {
+        double *cur = smem + (ch & 1) * 2 * GPCC_CHUNK;
+        if (ch + 1 < 8)
+            gpcc_dma_chunk(gA + (ch + 1) * GPCC_CHUNK, gB + (ch + 1) * GPCC_CHUNK, smem + ((ch + 1) & 1) * 2 * GPCC_CHUNK,
+                           wave, lane);
+        d2 a[2];
+        gpcc_load_frag(cur, wave * 16 + lr, q, sw, a[0], a[1]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    T[(wc * 4 + fn) * GPCC_CHUNK + (wr * 64 + fm * 16 + q + 4 * r) * GPCC_KC + lr] = -acc[fm][fn][r];
-    } else {
-        double wv[4];
+        for (int h = 0; h < 2; ++h) {  // column fragments in two groups of 4 (register budget)
+            if (4 * h + 3 < ch) continue;   // fragments left of chunk ch see only zeros of inv(L_kk)
+            d2 b[4][2];
 #pragma unroll
-        for (int fn = 0; fn < 4; ++fn) wv[fn] = c.w[(long)slot * c.Np + k * GPCC_TILE + wc * 64 + fn * 16 + lr];
-        double *red = smem;  // [2][128]; the operand ring is dead after the last barrier
+            for (int f = 0; f < 4; ++f)
+                if (4 * h + f >= ch) gpcc_load_frag(cur + GPCC_CHUNK, (4 * h + f) * 16 + lr, q, sw, b[f][0], b[f][1]);
 #pragma unroll
-        for (int fm = 0; fm < 4; ++fm)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int R = wr * 64 + fm * 16 + q + 4 * r;
-                double p = 0.0;
-#pragma unroll
-                for (int fn = 0; fn < 4; ++fn) {
-                    const double xv = acc[fm][fn][r];
-                    T[(wc * 4 + fn) * GPCC_CHUNK + R * GPCC_KC + lr] = xv;
-                    p += xv * wv[fn];
-                }
-                p += __shfl_xor(p, 1);
-                p += __shfl_xor(p, 2);
-                p += __shfl_xor(p, 4);
-                p += __shfl_xor(p, 8);
-                if (lr == 0) red[wc * 128 + R] = p;
-            }
-        __syncthreads();
-        if (tid < 128) {
-            double *zp = c.z + (long)slot * c.Np + I * GPCC_TILE + tid;
-            *zp = *zp - (red[tid] + red[128 + tid]);
+                for (int f = 0; f < 4; ++f)
+                    if (4 * h + f >= ch)
+                        acc[4 * h + f] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s >> 1][s & 1], b[f][s >> 1][s & 1],
+                                                                              acc[4 * h + f], 0, 0, 0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    double *zp = c.z + (long)slot * c.Np + I * GPCC_TILE;
+    double wv[8];
+#pragma unroll
+    for (int fn = 0; fn < 8; ++fn) wv[fn] = c.w[(long)slot * c.Np + k * GPCC_TILE + fn * 16 + lr];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int R = wave * 16 + q + 4 * r;
+        double p = 0.0;
+#pragma unroll
+        for (int fn = 0; fn < 8; ++fn) {
+            const double xv = acc[fn][r];
+            T[gpcc_elem_off(R, fn * 16 + lr)] = xv;
+            p += xv * wv[fn];
+        }
+        p += __shfl_xor(p, 1);
+        p += __shfl_xor(p, 2);
+        p += __shfl_xor(p, 4);
+        p += __shfl_xor(p, 8);
+        if (lr == 0) zp[R] = zp[R] - p;
     }
 }
 
@@ -349,7 +405,8 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
     double *tiles = c.tiles + (long)slot * c.slot_stride;
     double *T = tiles + gpcc_tile_off(k, k);
     for (int e = tid; e < GPCC_TILE_ELEMS; e += 256) {
-        const int ch = e >> 11, rem = e & 2047, r = rem >> 4, kk = rem & 15;
+        const int ch = e >> 11, rem = e & 2047, r = rem >> 4, ks = rem & 15;  // ks: storage position
+        const int kk = ((((ks >> 1) ^ gpcc_sw(r)) << 1) | (ks & 1));
         sT[r * GPCC_DIAG_LD + ch * 16 + kk] = T[e];
     }
     if (tid < GPCC_TILE) sz[tid] = c.z[(long)slot * c.Np + k * GPCC_TILE + tid];
@@ -417,7 +474,8 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
     // ---- write inv(L_kk) (B operand of the panel solve) and L_kk, both in tile layout
     double *Linv = c.linv + (long)slot * GPCC_TILE_ELEMS;
     for (int e = tid; e < GPCC_TILE_ELEMS; e += 256) {
-        const int ch = e >> 11, rem = e & 2047, r = rem >> 4, col = ch * 16 + (rem & 15);
+        const int ch = e >> 11, rem = e & 2047, r = rem >> 4, ks = rem & 15;
+        const int col = ch * 16 + ((((ks >> 1) ^ gpcc_sw(r)) << 1) | (ks & 1));
         Linv[e] = (col <= r) ? sT[r * GPCC_DIAG_LD + col] : 0.0;
         T[e] = (col < r) ? sT[col * GPCC_DIAG_LD + r] : ((col == r) ? sD[r] : 0.0);
     }

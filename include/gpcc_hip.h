@@ -57,8 +57,9 @@ int gpcc_create(gpcc_handle_t *handle, int L, const int *Nl, const double *t, co
                 const double *sigma, int kernel_id, int marginalise_b, int precision, int device_id);
 int gpcc_destroy(gpcc_handle_t handle);
 
-/* Tunables, before the first evaluation: "streams" (concurrent groups, default 2),
- * "slots_per_stream" (matrices resident per group, default 64), "lds_dma" (0/1). */
+/* Tunables: "streams" (groups in flight on separate HIP streams, default 1), "slots_per_stream"
+ * (evaluations resident per group, default 256 = one diagonal-block workgroup per CU, capped so
+ * the workspace stays under 64 GiB); "lds_dma" is accepted for compatibility (always on). */
 int gpcc_set_option(gpcc_handle_t handle, const char *key, long value);
 long gpcc_get_option(gpcc_handle_t handle, const char *key);
 
