@@ -18,8 +18,9 @@
 #define GPCC_CHUNK (GPCC_TILE * GPCC_KC)        /* 2048 doubles = 16 KiB */
 #define GPCC_TILE_ELEMS (GPCC_TILE * GPCC_TILE) /* 16384 doubles = 128 KiB */
 #define GPCC_MAXL 8
-#define GPCC_DIAG_LD 129
-#define GPCC_DIAG_LDS_BYTES ((GPCC_TILE * GPCC_DIAG_LD + 3 * GPCC_TILE + 256) * 8 + 16)
+#define GPCC_DIAG_LD 130
+#define GPCC_DINV_LD 17
+#define GPCC_DIAG_LDS_BYTES ((GPCC_TILE * GPCC_DIAG_LD + 8 * 16 * GPCC_DINV_LD + 2 * GPCC_TILE) * 8 + 16)
 #define GPCC_GEMM_LDS_BYTES (2 * 2 * GPCC_CHUNK * 8)
 #define GPCC_GEMM_THREADS 512
 
@@ -374,24 +375,35 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_trsm(GpccCtx c, GpccGroup g
 }
 
 // ------------------------------------------------------------------------------------------
-// gpcc_diag_factor: step k's 128x128 diagonal block, one workgroup per evaluation, all in LDS:
-// potf2 (dpotf2), its triangular inverse (feeds the MFMA panel solve), sum log L_ii (logdet of
-// PDMat), w_k = inv(L_kk) z_k and |w_k|^2 (sqmahal); the last step writes
-// loglik = -(N log 2pi + 2 sum log L_ii)/2 - |w|^2/2  (Distributions.logpdf, marginaliseb.jl:139).
-// The scaled column j of L is parked in the upper triangle (row j), so the raw column can still
-// be read by the trailing update of the same step: one barrier per column.
+// gpcc_diag_factor: step k's 128x128 diagonal block, one workgroup (4 waves) per evaluation, all in
+// LDS: blocked dpotf2 (16-wide panels), its triangular inverse (the B operand of the MFMA panel
+// solve), sum log L_ii (logdet of PDMat), w_k = inv(L_kk) z_k and |w_k|^2 (sqmahal); the last step
+// writes loglik = -(N log 2pi + 2 sum log L_ii)/2 - |w|^2/2  (Distributions.logpdf, marginaliseb.jl:139).
+//   per 16-block jb: (1) wave 0 factors the 16x16 diagonal block and inverts it in REGISTERS (lane =
+//   row resp. column, broadcasts by v_readlane);  (2) panel rows below: P = A inv(D)^T by MFMA;
+//   (3) trailing update C -= P P^T by MFMA.  Then inv(L) is assembled block-wise by MFMA: the
+//   accumulator of S = sum_m L[i][m] X[m][j] is directly the B operand of X[i][j] = -inv(D_i) S.
+//   X's off-diagonal blocks live transposed in the (dead) upper triangle of the LDS image.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double gpcc_bcast(double v, int srclane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, int k)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *sT = smem;                           // 128 x 129
-    double *sD = sT + GPCC_TILE * GPCC_DIAG_LD;  // L_jj
-    double *sI = sD + GPCC_TILE;                 // 1 / L_jj
-    double *sz = sI + GPCC_TILE;                 // z_k, later w_k
-    double *sr = sz + GPCC_TILE;                 // 256 reduction scratch
-    int *sbad = (int *)(sr + 256);
+    constexpr int LD = GPCC_DIAG_LD, DLD = GPCC_DINV_LD;
+    double *sT = smem;                      // 128 x LD: lower = A -> L ; upper = inv(L)^T off-diagonal blocks
+    double *sDinv = sT + GPCC_TILE * LD;    // 8 x 16 x DLD: inverses of the 16x16 diagonal blocks
+    double *sz = sDinv + 8 * 16 * DLD;      // z_k, later w_k^2
+    double *sr = sz + GPCC_TILE;            // 128 log L_ii
+    int *sbad = (int *)(sr + GPCC_TILE);
 
-    const int tid = threadIdx.x, m = blockIdx.x, slot = g.slot0 + m;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, q = lane >> 4;
+    const int m = blockIdx.x, slot = g.slot0 + m;
     const bool last = (k == c.nt - 1);
     const int inf = c.info[slot];
     if (inf != 0) {
@@ -401,62 +413,127 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
         }
         return;
     }
-    const int ty = tid >> 4, tx = tid & 15;
     double *tiles = c.tiles + (long)slot * c.slot_stride;
     double *T = tiles + gpcc_tile_off(k, k);
     for (int e = tid; e < GPCC_TILE_ELEMS; e += 256) {
         const int ch = e >> 11, rem = e & 2047, r = rem >> 4, ks = rem & 15;  // ks: storage position
         const int kk = ((((ks >> 1) ^ gpcc_sw(r)) << 1) | (ks & 1));
-        sT[r * GPCC_DIAG_LD + ch * 16 + kk] = T[e];
+        sT[r * LD + ch * 16 + kk] = T[e];
     }
     if (tid < GPCC_TILE) sz[tid] = c.z[(long)slot * c.Np + k * GPCC_TILE + tid];
     if (tid == 0) *sbad = 0;
 
-    // ---- potf2, right-looking, one barrier per column
-    for (int j = 0; j < GPCC_TILE; ++j) {
+    for (int jb = 0; jb < 8; ++jb) {
+        const int r0 = jb * 16;
         __syncthreads();
-        const double d = sT[j * GPCC_DIAG_LD + j];
-        if (!(d > 0.0) && tid == 0 && *sbad == 0) *sbad = j + 1;  // also catches NaN
-        const double s = sqrt(d), inv = 1.0 / s, invd = 1.0 / d;
-        if (tid == 0) { sD[j] = s; sI[j] = inv; }
-        for (int i = j + 1 + tid; i < GPCC_TILE; i += 256) sT[j * GPCC_DIAG_LD + i] = sT[i * GPCC_DIAG_LD + j] * inv;
-        for (int i = j + 1 + ty; i < GPCC_TILE; i += 16) {
-            const double aij = sT[i * GPCC_DIAG_LD + j] * invd;
-            for (int cc = j + 1 + tx; cc <= i; cc += 16) sT[i * GPCC_DIAG_LD + cc] -= aij * sT[cc * GPCC_DIAG_LD + j];
+        if (wave == 0) {
+            // ---- (1) 16x16 potf2 + inverse in registers: lane l (< 16) owns row l of D
+            const int l = lr;  // lanes >= 16 shadow lanes 0..15 (in-bounds loads, results unused)
+            double a[16], invs[16];
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) a[cc] = (cc <= l) ? sT[(r0 + l) * LD + r0 + cc] : 0.0;
+            int bad = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double d = gpcc_bcast(a[j], j);
+                if (!(d > 0.0) && bad == 0) bad = j + 1;  // also catches NaN
+                const double sq = sqrt(d), inv = 1.0 / sq;
+                invs[j] = inv;
+                a[j] = (l == j) ? sq : a[j] * inv;
+#pragma unroll
+                for (int cc = j + 1; cc < 16; ++cc) {
+                    const double lcj = gpcc_bcast(a[j], cc);  // L[cc][j]
+                    a[cc] = (l >= cc) ? a[cc] - a[j] * lcj : 0.0;
+                }
+            }
+            // inverse: lane cx owns column cx of X = inv(L_D):  x[i] = (delta - sum_{j<i} L[i][j] x[j]) / L[i][i]
+            double xcol[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                double accv = (i == l) ? 1.0 : 0.0;
+#pragma unroll
+                for (int j = 0; j < i; ++j) accv -= gpcc_bcast(a[j], i) * xcol[j];
+                xcol[i] = accv * invs[i];
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc) {
+                    if (cc <= l) sT[(r0 + l) * LD + r0 + cc] = a[cc];     // L_D (lower, diagonal included)
+                    sDinv[(jb * 16 + cc) * DLD + l] = xcol[cc];            // X[cc][l] (zero above the diagonal)
+                }
+                if (lane == 0 && bad && *sbad == 0) *sbad = r0 + bad;
+            }
         }
+        __syncthreads();
+        // ---- (2) panel: P = A[rf, jb] inv(D)^T for the row fragments below, in place
+        for (int rf = jb + 1 + wave; rf < 8; rf += 4) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                av[s2] = sT[(rf * 16 + lr) * LD + r0 + q + 4 * s2];
+                bv[s2] = sDinv[(jb * 16 + lr) * DLD + q + 4 * s2];   // B[k][c] = inv(D)[c][k]
+            }
+            d4 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[s2], x, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sT[(rf * 16 + q + 4 * r) * LD + r0 + lr] = x[r];
+        }
+        __syncthreads();
+        // ---- (3) trailing update C[rf][cf] -= P_rf P_cf^T, jb < cf <= rf
+        int cnt = 0;
+        for (int rf = jb + 1; rf < 8; ++rf)
+            for (int cf = jb + 1; cf <= rf; ++cf, ++cnt) {
+                if ((cnt & 3) != wave) continue;
+                d4 x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = sT[(rf * 16 + q + 4 * r) * LD + cf * 16 + lr];
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+                    x = __builtin_amdgcn_mfma_f64_16x16x4f64(-sT[(rf * 16 + lr) * LD + r0 + q + 4 * s2],
+                                                             sT[(cf * 16 + lr) * LD + r0 + q + 4 * s2], x, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sT[(rf * 16 + q + 4 * r) * LD + cf * 16 + lr] = x[r];
+            }
     }
     __syncthreads();
-    // now: upper triangle row j = column j of L (below the diagonal), sD = diag(L)
-    double part = (tid < GPCC_TILE) ? log(sD[tid]) : 0.0;
-    sr[tid] = part;
-    // ---- X = inv(L): forward substitution on the identity, X lives in the dead lower triangle
-    for (int i = ty; i < GPCC_TILE; i += 16)
-        for (int cc = tx; cc <= i; cc += 16) sT[i * GPCC_DIAG_LD + cc] = (i == cc) ? 1.0 : 0.0;
-    for (int j = 0; j < GPCC_TILE; ++j) {
+    if (tid < GPCC_TILE) sr[tid] = log(sT[tid * LD + tid]);
+    // ---- X = inv(L) block-wise, level d = i - j (blocks of one level are independent)
+    for (int d = 1; d < 8; ++d) {
         __syncthreads();
-        const double ij = sI[j];
-        for (int i = j + 1 + ty; i < GPCC_TILE; i += 16) {
-            const double lij = sT[j * GPCC_DIAG_LD + i] * ij;  // L_ij / L_jj
-            for (int cc = tx; cc <= j; cc += 16) sT[i * GPCC_DIAG_LD + cc] -= lij * sT[j * GPCC_DIAG_LD + cc];
+        for (int j = wave; j + d < 8; j += 4) {
+            const int i = j + d;
+            d4 S = {0.0, 0.0, 0.0, 0.0};
+            for (int mm = j; mm < i; ++mm) {
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    const double av = sT[(i * 16 + lr) * LD + mm * 16 + q + 4 * s2];               // L[i][mm]
+                    const double bv = (mm == j) ? sDinv[(j * 16 + q + 4 * s2) * DLD + lr]          // X[j][j][k][c]
+                                                : sT[(j * 16 + lr) * LD + mm * 16 + q + 4 * s2];   // X[mm][j]^T
+                    S = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, S, 0, 0, 0);
+                }
+            }
+            d4 Y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)  // the accumulator S (row q+4r, col lr) IS the B operand of k-step r
+                Y = __builtin_amdgcn_mfma_f64_16x16x4f64(-sDinv[(i * 16 + lr) * DLD + q + 4 * r], S[r], Y, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sT[(j * 16 + lr) * LD + i * 16 + q + 4 * r] = Y[r];   // X[i][j] transposed
         }
-    }
-    __syncthreads();
-    for (int i = ty; i < GPCC_TILE; i += 16) {
-        const double ii = sI[i];
-        for (int cc = tx; cc <= i; cc += 16) sT[i * GPCC_DIAG_LD + cc] *= ii;
     }
     __syncthreads();
     // ---- w_k = X z_k
     double wi = 0.0;
     if (tid < GPCC_TILE) {
-        for (int cc = 0; cc <= tid; ++cc) wi += sT[tid * GPCC_DIAG_LD + cc] * sz[cc];
+        const int bi = tid >> 4;
+        for (int cc = 0; cc < bi * 16; ++cc) wi += sT[cc * LD + tid] * sz[cc];
+        for (int cc = bi * 16; cc <= tid; ++cc) wi += sDinv[(bi * 16 + (tid & 15)) * DLD + (cc & 15)] * sz[cc];
         c.w[(long)slot * c.Np + k * GPCC_TILE + tid] = wi;
     }
-    // reductions: sr holds log L_ii; reduce both sums by thread 0 in a fixed order (deterministic)
     __syncthreads();
     if (tid < GPCC_TILE) sz[tid] = wi * wi;
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0) {  // fixed summation order: deterministic
         double ld = 0.0, qd = 0.0;
         for (int i = 0; i < GPCC_TILE; ++i) { ld += sr[i]; qd += sz[i]; }
         ld += c.logdet[slot];
@@ -476,8 +553,13 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
     for (int e = tid; e < GPCC_TILE_ELEMS; e += 256) {
         const int ch = e >> 11, rem = e & 2047, r = rem >> 4, ks = rem & 15;
         const int col = ch * 16 + ((((ks >> 1) ^ gpcc_sw(r)) << 1) | (ks & 1));
-        Linv[e] = (col <= r) ? sT[r * GPCC_DIAG_LD + col] : 0.0;
-        T[e] = (col < r) ? sT[col * GPCC_DIAG_LD + r] : ((col == r) ? sD[r] : 0.0);
+        double xv = 0.0, lv = 0.0;
+        if (col <= r) {
+            xv = ((col >> 4) == (r >> 4)) ? sDinv[r * DLD + (col & 15)] : sT[col * LD + r];
+            lv = sT[r * LD + col];
+        }
+        Linv[e] = xv;
+        T[e] = lv;
     }
 }
 
