@@ -45,6 +45,20 @@ def update_flops_per_eval(N):
     return total, per_step
 
 
+def pmc_traffic(kernel, slots, N):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (bench.py cannot
+    collect PMC counters itself); None if no summary matches this configuration."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("slots") != slots or d.get("N") != N:
+            return None, None
+        return d["kernels"][kernel]["hbm_bytes_per_launch"], "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,9 +162,10 @@ def main():
             avg_ms = total_ms / launches
             flops_per_launch = flops_eval * G / launches      # algorithmic flops / launch (average over steps k)
             achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "gpcc_gemm_nt<false,*> (panel update)", "achieved": round(achieved, 3),
+            traffic, tsrc = pmc_traffic("gpcc_panel_update", obj.get_option("slots_per_stream"), N)
+            roofline = {"bound": "mfma", "kernel": "gpcc_panel_update", "achieved": round(achieved, 3),
                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
-                        "traffic": None, "launches": launches, "avg_launch_ms": round(avg_ms, 4),
+                        "traffic": traffic, "traffic_source": tsrc, "launches": launches, "avg_launch_ms": round(avg_ms, 4),
                         "algorithmic_flops_per_launch": flops_per_launch,
                         "other_kernels_ms": {k: round(v[1], 3) for k, v in prof.items()}}
             # the HBM-bound assembly kernel, reported beside it

@@ -70,27 +70,66 @@ __device__ __forceinline__ int gpcc_elem_off(int r, int col)
 }
 
 // ------------------------------------------------------------------------------------------
-// Stationary kernels, /root/reference/src/util.jl:15-52, operation order kept (no contraction)
-// so that the element matches the CPU evaluation to the last bit up to exp()'s own rounding.
+// Stationary kernels, /root/reference/src/util.jl:15-52.  The assembly is HBM-write-bound only if
+// an element costs ~30 instructions, so: the divisions by rho become multiplications by
+// per-evaluation reciprocals (GpccKernelConst), and exp() of a non-positive argument is a
+// straight-line Cody-Waite reduction + degree-13 Taylor/Horner + v_ldexp_f64 (|r| <= ln2/2:
+// truncation 4e-18, total error ~1 ulp, like libm's).  Each element therefore agrees with the
+// reference's expression to a few ulp (tests: 1e-13 relative), not bit for bit.
 // ------------------------------------------------------------------------------------------
+struct GpccKernelConst { double c1, c2; };
+
 template <int KID>
-__device__ __forceinline__ double gpcc_kernel_eval(double xi, double xj, double rho)
+__device__ __forceinline__ GpccKernelConst gpcc_kernel_const(double rho)
 {
-#pragma clang fp contract(off)
+    GpccKernelConst kc;
+    if (KID == 1) kc.c1 = 1.0 / (2.0 * rho);   // rbf: exp(-0.5 d^2 / (2 rho)) -- rho linear, as the reference
+    else kc.c1 = 1.0 / rho;
+    kc.c2 = (KID == 3) ? 1.0 / (3.0 * (rho * rho)) : 0.0;
+    return kc;
+}
+
+__device__ __forceinline__ double gpcc_exp_nonpos(double x)  // x <= 0
+{
+    const double L2E = 1.4426950408889634074, LN2HI = 6.93147180369123816490e-01, LN2LO = 1.90821492927058770002e-10;
+    const double n = rint(x * L2E);
+    double r = fma(-n, LN2HI, x);
+    r = fma(-n, LN2LO, r);
+    double p = 1.6059043836821614599e-10;  // 1/13!
+    p = fma(p, r, 2.0876756987868098979e-09);
+    p = fma(p, r, 2.5052108385441718775e-08);
+    p = fma(p, r, 2.7557319223985890653e-07);
+    p = fma(p, r, 2.7557319223985890653e-06);
+    p = fma(p, r, 2.4801587301587301587e-05);
+    p = fma(p, r, 1.9841269841269841270e-04);
+    p = fma(p, r, 1.3888888888888888889e-03);
+    p = fma(p, r, 8.3333333333333333333e-03);
+    p = fma(p, r, 4.1666666666666666667e-02);
+    p = fma(p, r, 1.6666666666666666667e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double nn = fmax(n, -1100.0);  // exp underflows to 0 well before; keeps the int conversion defined
+    return ldexp(p, (int)nn);
+}
+
+template <int KID>
+__device__ __forceinline__ double gpcc_kernel_eval(double xi, double xj, GpccKernelConst kc)
+{
     if (KID == 0) {  // OU: exp(-|xi-xj|/rho)
-        double r = fabs(xi - xj);
-        return exp(-r / rho);
-    } else if (KID == 1) {  // rbf: exp(-0.5 (xi-xj)^2 / (2 rho))  -- rho linear, as the reference
-        double d = xi - xj;
-        return exp(-0.5 * (d * d) / (2.0 * rho));
-    } else if (KID == 2) {  // matern32
-        double r = fabs(xi - xj);
-        const double s3 = 1.7320508075688772;  // sqrt(3.0)
-        return (1.0 + s3 * r / rho) * exp(-s3 * r / rho);
-    } else {  // matern52
-        double r = fabs(xi - xj);
-        const double s5 = 2.23606797749979;  // sqrt(5.0)
-        return (1.0 + s5 * r / rho + (5.0 * (r * r)) / (3.0 * (rho * rho))) * exp(-s5 * r / rho);
+        const double r = fabs(xi - xj);
+        return gpcc_exp_nonpos(-(r * kc.c1));
+    } else if (KID == 1) {  // rbf
+        const double d = xi - xj;
+        return gpcc_exp_nonpos(-((0.5 * (d * d)) * kc.c1));
+    } else if (KID == 2) {  // matern32: (1 + sqrt3 r/rho) exp(-sqrt3 r/rho)
+        const double r = fabs(xi - xj);
+        const double t = (1.7320508075688772 * r) * kc.c1;
+        return (1.0 + t) * gpcc_exp_nonpos(-t);
+    } else {  // matern52: (1 + sqrt5 r/rho + 5 r^2/(3 rho^2)) exp(-sqrt5 r/rho)
+        const double r = fabs(xi - xj);
+        const double t = (2.23606797749979 * r) * kc.c1;
+        return (1.0 + t + (5.0 * (r * r)) * kc.c2) * gpcc_exp_nonpos(-t);
     }
 }
 
@@ -110,9 +149,10 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
     const int m = blockIdx.y, slot = g.slot0 + m, tid = threadIdx.x;
     const double *delays = g.delays + (long)(g.first + m) * c.L;
     const double *alpha = g.alpha + (long)(g.first + m) * c.L;
+    const GpccKernelConst kc = gpcc_kernel_const<KID>(g.rho[g.first + m]);
     const double rho = g.rho[g.first + m];
 
-    __shared__ double su[2][GPCC_TILE], sa[2][GPCC_TILE], ssig[GPCC_TILE], ssb[GPCC_MAXL];
+    __shared__ __attribute__((aligned(16))) double su[2][GPCC_TILE], sa[2][GPCC_TILE], ssig[GPCC_TILE], ssb[GPCC_MAXL];
     __shared__ int sb[2][GPCC_TILE];
     if (tid < GPCC_MAXL) ssb[tid] = (tid < c.L) ? c.sigma_b[tid] : 0.0;
 
@@ -142,28 +182,34 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
     double *T = c.tiles + (long)slot * c.slot_stride + gpcc_tile_off(I, J);
     const bool diag = (I == J);
     const bool mb = c.marginalise_b != 0;
-#pragma unroll 4
-    for (int it = 0; it < 32; ++it) {
-        const int e = tid + 256 * it;  // 16-byte piece index inside the tile
-        const int ch = e >> 10, rem = e & 1023, r = rem >> 3, col = ch * 16 + (((rem & 7) ^ gpcc_sw(r)) << 1);
-        d2 v;
+    const int sp = tid & 7;  // this thread's 16-byte storage slot in every row it writes
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma clang fp contract(off)
-            const int cc = col + h;
-            const int br = sb[0][r], bc = sb[1][cc];
-            double val;
-            if (br < 0 || bc < 0) {
-                val = (diag && r == cc) ? 1.0 : 0.0;  // identity padding: log 1 = 0, resid 0
-            } else {
-                const double kv = gpcc_kernel_eval<KID>(su[0][r], su[1][cc], rho);
-                val = (sa[0][r] * sa[1][cc]) * kv;
-                if (diag && r == cc) val = val + ssig[r];      // + Sobs
-                if (mb && br == bc) val = val + ssb[br];        // + B = Q Sigma_b Q'
+    for (int j = 0; j < 4; ++j) {
+        const int r = (tid >> 3) + 32 * j;  // row data stays in registers across the 8 chunks
+        const int br = sb[0][r];
+        const double ur = su[0][r], ar = sa[0][r], sg = ssig[r];
+        const double bterm = (mb && br >= 0) ? ssb[br] : 0.0;
+        const int cs = (sp ^ gpcc_sw(r)) << 1;  // logical column (inside a chunk) stored in slot sp
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            const int col = ch * 16 + cs;
+            const d2 uc = *(const d2 *)&su[1][col];
+            const d2 ac = *(const d2 *)&sa[1][col];
+            const int bc0 = sb[1][col], bc1 = sb[1][col + 1];
+            d2 v;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int cc = col + h;
+                const int bc = h ? bc1 : bc0;
+                const double kv = gpcc_kernel_eval<KID>(ur, uc[h], kc);  // x - delays[i] vs y - delays[j]
+                double val = (ar * ac[h]) * kv;                            // scale[i]*scale[j]*kernel
+                if (diag && r == cc) val = val + sg;                       // + Sobs
+                if (br == bc) val = val + bterm;                           // + B = Q Sigma_b Q'
+                if (br < 0 || bc < 0) val = (diag && r == cc) ? 1.0 : 0.0;  // identity padding
+                v[h] = val;
             }
-            v[h] = val;
+            *(d2 *)(T + ch * GPCC_CHUNK + r * GPCC_KC + sp * 2) = v;
         }
-        *(d2 *)(T + (long)e * 2) = v;
     }
 }
 
@@ -589,11 +635,10 @@ template <int KID>
 __global__ void gpcc_covariance_kernel(long nx, long ny, const double *xu, const double *xs, const double *yu,
                                        const double *ys, double rho, double *out)
 {
-#pragma clang fp contract(off)
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nx * ny) return;
     const long r = idx % nx, col = idx / nx;
-    out[idx] = (xs[r] * ys[col]) * gpcc_kernel_eval<KID>(xu[r], yu[col], rho);
+    out[idx] = (xs[r] * ys[col]) * gpcc_kernel_eval<KID>(xu[r], yu[col], gpcc_kernel_const<KID>(rho));
 }
 
 // ------------------------------------------------------------------------------------------
