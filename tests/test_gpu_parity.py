@@ -171,3 +171,61 @@ def test_full_size_properties_and_oracle(gp, oracle):
     assert _rel(ll_p, ll[:3]) <= 1e-9
     p = gp.getprobabilities(ll)
     assert abs(p.sum() - 1) < 1e-12
+
+
+# ---- BASELINE.json configurations (parity-test cases; bench.py measures configs "N=4096 Matern-3/2") ----
+def test_cfg2_two_band_1024_grid256(gp, oracle):
+    """cfg2: 2 x 1024, Matern-3/2 fp64, 256-point delay grid: every 32nd point against the oracle."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([1024, 1024], seed=1)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    grid = np.linspace(0.0, 20.0, 256)
+    delays = np.stack([np.zeros_like(grid), grid], 1)
+    with gp.Objective(t, y, s, gp.matern32) as obj:
+        ll, info = obj.loglik_batch(delays, np.tile(alpha, (256, 1)), np.full(256, rho))
+    assert (info == 0).all()
+    idx = np.arange(0, 256, 32)
+    ref, _ = oracle.loglik_batch("matern32", t, y, s, delays[idx], np.tile(alpha, (len(idx), 1)),
+                                 np.full(len(idx), rho), True, nthreads=8)
+    assert _rel(ll[idx], ref) <= LL_RTOL
+    p = gp.getprobabilities(ll)
+    assert abs(p.sum() - 1) < 1e-12
+
+
+@pytest.mark.parametrize("kname", ["OU", "rbf", "matern52"])
+def test_cfg3_other_kernels_full_size(gp, oracle, kname):
+    """cfg3: 2 x 2048 with the other three kernels (Matern-3/2 is covered above): one oracle sample
+    each plus the delay-shift invariance over a small grid."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([2048, 2048], seed=2)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    grid = np.linspace(0.0, 20.0, 6)
+    delays = np.stack([np.zeros_like(grid), grid], 1)
+    with gp.Objective(t, y, s, kname) as obj:
+        ll, info = obj.loglik_batch(delays, np.tile(alpha, (6, 1)), np.full(6, rho))
+        ll_s, info_s = obj.loglik_batch(delays - 1.25, np.tile(alpha, (6, 1)), np.full(6, rho))
+    ok = info == 0
+    assert ok.any() and np.array_equal(ok, info_s == 0)
+    assert _rel(ll_s[ok], ll[ok]) <= 1e-8
+    j = int(np.flatnonzero(ok)[0])
+    ref, rinfo = oracle.loglik_batch(kname, t, y, s, delays[[j]], [alpha], [rho], True)
+    assert rinfo[0] == 0 and _rel(ll[[j]], ref) <= LL_RTOL
+
+
+def test_cfg4_three_band_2d_grid(gp, oracle):
+    """cfg4: 3 x 1365 (N = 4095: ragged last tile), Matern-3/2, a 6 x 6 corner of the 2-D delay grid,
+    flattened like README.md:233-235; two points against the oracle."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([1365, 1365, 1365], seed=3)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    g1 = np.linspace(0.5, 6.0, 6)
+    d2, d3 = np.meshgrid(g1, g1, indexing="ij")
+    delays = np.stack([np.zeros(36), d2.ravel(), d3.ravel()], 1)
+    with gp.Objective(t, y, s, gp.matern32) as obj:
+        ll, info = obj.loglik_batch(delays, np.tile(alpha, (36, 1)), np.full(36, rho))
+    assert (info == 0).all()
+    ref, rinfo = oracle.loglik_batch("matern32", t, y, s, delays[[4, 29]], np.tile(alpha, (2, 1)),
+                                     np.full(2, rho), True, nthreads=2)
+    assert (rinfo == 0).all() and _rel(ll[[4, 29]], ref) <= LL_RTOL
+    post = gp.getprobabilities(ll.reshape(6, 6))
+    assert post.shape == (6, 6) and abs(post.sum() - 1) < 1e-12
