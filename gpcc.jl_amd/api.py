@@ -250,6 +250,41 @@ class Objective:
             _raise_reference_error(e)
         return Lf.T, info.value
 
+    # -- prediction / posterior of the offsets (reference: marginaliseb.jl:248-252, :259-343) ----------------
+    def predict(self, delays, alpha, rho, ttest):
+        """predictTest(ttest::Vector{Vector}) at (tau, alpha, rho): joint (mu_pred, Sigma_pred) for the test
+        times ttest[l] of every band, Sigma_pred including JITTER*I (marginaliseb.jl:259-289)."""
+        assert len(ttest) == self.L
+        delays, alpha = _d(delays), _d(alpha)
+        Nt, tt = _flatten(ttest)
+        n = int(Nt.sum())
+        mu = np.empty(n, dtype=np.float64)
+        Sig = np.empty((n, n), dtype=np.float64)
+        ll, info = ctypes.c_double(0.0), ctypes.c_int(0)
+        try:
+            self._chk(_capi.load().gpcc_predict(self._h, _dp(delays), _dp(alpha), float(rho), _ip(Nt), _dp(tt), _dp(mu),
+                                                _dp(Sig), ctypes.byref(ll), ctypes.byref(info)))
+        except GpccError as e:
+            _raise_reference_error(e)
+        if info.value > 0:
+            raise PosDefException(info.value)
+        return mu, Sig.T
+
+    def posterior_offsets(self, delays, alpha, rho):
+        """(mu_postb, Sigma_postb) of marginaliseb.jl:248-252 (the reference wraps them in MvNormal)."""
+        delays, alpha = _d(delays), _d(alpha)
+        mu = np.empty(self.L, dtype=np.float64)
+        Sig = np.empty((self.L, self.L), dtype=np.float64)
+        info = ctypes.c_int(0)
+        try:
+            self._chk(_capi.load().gpcc_posterior_offsets(self._h, _dp(delays), _dp(alpha), float(rho), _dp(mu), _dp(Sig),
+                                                          ctypes.byref(info)))
+        except GpccError as e:
+            _raise_reference_error(e)
+        if info.value > 0:
+            raise PosDefException(info.value)
+        return mu, Sig.T
+
     # -- profiling (bench.py) ------------------------------------------------------------------------
     def profile(self, on):
         self._chk(_capi.load().gpcc_profile_enable(self._h, int(bool(on))))

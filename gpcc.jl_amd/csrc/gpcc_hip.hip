@@ -24,8 +24,10 @@ struct gpcc_handle_s {
     int Nl[GPCC_MAXL];
     double mean_b[GPCC_MAXL], sigma_b[GPCC_MAXL];
     std::vector<double> resid_host;
-    double *d_t = nullptr, *d_sig2 = nullptr, *d_resid = nullptr;
+    double *d_t = nullptr, *d_sig2 = nullptr, *d_resid = nullptr, *d_yv = nullptr;
     int *d_band = nullptr;
+    std::vector<double> t_host, y_host, sig2_host;
+    std::vector<int> band_host;
     // options
     int streams = 1, slots_per_stream = 256, lds_dma = 1;
     // workspace
@@ -125,7 +127,7 @@ extern "C" int gpcc_create(gpcc_handle_t *out, int L, const int *Nl, const doubl
     h->kernel_id = kernel_id;
     h->mb = marginalise_b ? 1 : 0;
     h->precision = precision;
-    std::vector<double> ht(h->Np, 0.0), hs(h->Np, 0.0), hr(h->Np, 0.0);
+    std::vector<double> ht(h->Np, 0.0), hs(h->Np, 0.0), hr(h->Np, 0.0), hy(h->Np, 0.0);
     std::vector<int> hb(h->Np, -1);
     long off = 0;
     for (int l = 0; l < L; ++l) {
@@ -143,10 +145,15 @@ extern "C" int gpcc_create(gpcc_handle_t *out, int L, const int *Nl, const doubl
             hs[off + n] = sigma[off + n] * sigma[off + n];  // Sobs = Diagonal(sigma.^2), :89
             hr[off + n] = y[off + n] - mean;                // Y - bbar (bbar = Q mu_b / Q b)
             hb[off + n] = l;
+            hy[off + n] = y[off + n];
         }
         off += Nl[l];
     }
     h->resid_host.assign(hr.begin(), hr.begin() + N);
+    h->t_host.assign(ht.begin(), ht.begin() + N);
+    h->y_host.assign(hy.begin(), hy.begin() + N);
+    h->sig2_host.assign(hs.begin(), hs.begin() + N);
+    h->band_host.assign(hb.begin(), hb.begin() + N);
 #define CR(call)                                                                                             \
     do {                                                                                                     \
         hipError_t e_ = (call);                                                                              \
@@ -160,10 +167,12 @@ extern "C" int gpcc_create(gpcc_handle_t *out, int L, const int *Nl, const doubl
     CR(hipMalloc(&h->d_t, nb));
     CR(hipMalloc(&h->d_sig2, nb));
     CR(hipMalloc(&h->d_resid, nb));
+    CR(hipMalloc(&h->d_yv, nb));
     CR(hipMalloc(&h->d_band, sizeof(int) * h->Np));
     CR(hipMemcpy(h->d_t, ht.data(), nb, hipMemcpyHostToDevice));
     CR(hipMemcpy(h->d_sig2, hs.data(), nb, hipMemcpyHostToDevice));
     CR(hipMemcpy(h->d_resid, hr.data(), nb, hipMemcpyHostToDevice));
+    CR(hipMemcpy(h->d_yv, hy.data(), nb, hipMemcpyHostToDevice));
     CR(hipMemcpy(h->d_band, hb.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice));
     CR(hipStreamCreateWithFlags(&h->main_stream, hipStreamNonBlocking));
     CR(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
@@ -192,7 +201,7 @@ extern "C" int gpcc_destroy(gpcc_handle_t h)
     hipDeviceSynchronize();
     for (auto &r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     free_workspace(h);
-    hipFree(h->d_t); hipFree(h->d_sig2); hipFree(h->d_resid); hipFree(h->d_band);
+    hipFree(h->d_t); hipFree(h->d_sig2); hipFree(h->d_resid); hipFree(h->d_band); hipFree(h->d_yv);
     hipFree(h->d_par); hipFree(h->d_out); hipFree(h->d_oinfo);
     if (h->main_stream) hipStreamDestroy(h->main_stream);
     if (h->ev_start) hipEventDestroy(h->ev_start);
@@ -272,10 +281,11 @@ static GpccCtx make_ctx(gpcc_handle_t h)
     GpccCtx c;
     c.tiles = h->d_tiles; c.linv = h->d_linv; c.z = h->d_z; c.w = h->d_w;
     c.logdet = h->d_logdet; c.quad = h->d_quad; c.info = h->d_info;
-    c.t = h->d_t; c.sig2 = h->d_sig2; c.resid = h->d_resid; c.band = h->d_band;
+    c.t = h->d_t; c.sig2 = h->d_sig2; c.resid = h->d_resid; c.band = h->d_band; c.yv = h->d_yv;
     for (int l = 0; l < GPCC_MAXL; ++l) c.sigma_b[l] = (l < h->L) ? h->sigma_b[l] : 0.0;
     c.slot_stride = h->slot_stride;
     c.L = h->L; c.N = h->N; c.Np = h->Np; c.nt = h->nt; c.kernel_id = h->kernel_id; c.marginalise_b = h->mb;
+    c.nt_fact = h->nt;
     return c;
 }
 
@@ -291,28 +301,36 @@ struct ProfScope {
     }
 };
 
-static void launch_assemble(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s)
+template <bool EXT>
+static void launch_assemble_t(const GpccCtx &c, const GpccGroup &g, hipStream_t s)
 {
-    ProfScope p(h, GPCC_PROF_ASSEMBLE, s);
     dim3 grid(c.nt * c.nt, g.cnt);
     switch (c.kernel_id) {
-    case 0: gpcc_assemble_tiles<0><<<grid, 256, 0, s>>>(c, g); break;
-    case 1: gpcc_assemble_tiles<1><<<grid, 256, 0, s>>>(c, g); break;
-    case 2: gpcc_assemble_tiles<2><<<grid, 256, 0, s>>>(c, g); break;
-    default: gpcc_assemble_tiles<3><<<grid, 256, 0, s>>>(c, g); break;
+    case 0: gpcc_assemble_tiles<0, EXT><<<grid, 256, 0, s>>>(c, g); break;
+    case 1: gpcc_assemble_tiles<1, EXT><<<grid, 256, 0, s>>>(c, g); break;
+    case 2: gpcc_assemble_tiles<2, EXT><<<grid, 256, 0, s>>>(c, g); break;
+    default: gpcc_assemble_tiles<3, EXT><<<grid, 256, 0, s>>>(c, g); break;
     }
 }
 
-// assemble + left-looking blocked Cholesky + fused forward solve for one group on stream s
-static int enqueue_group(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s, bool factor = true)
+static void launch_assemble(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s, bool ext)
 {
-    launch_assemble(h, c, g, s);
+    ProfScope p(h, GPCC_PROF_ASSEMBLE, s);
+    if (ext) launch_assemble_t<true>(c, g, s);
+    else launch_assemble_t<false>(c, g, s);
+}
+
+// assemble + left-looking blocked Cholesky + fused forward solve for one group on stream s
+static int enqueue_group(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s, bool factor = true,
+                         bool ext = false)
+{
+    launch_assemble(h, c, g, s, ext);
     if (!factor) return 0;
     const int cnt8 = 8 * ((g.cnt + 7) / 8);
-    for (int k = 0; k < c.nt; ++k) {
+    for (int k = 0; k < c.nt_fact; ++k) {
         if (k > 0) {
             ProfScope p(h, GPCC_PROF_PANEL_UPDATE, s);
-            gpcc_panel_update<<<cnt8 * (c.nt - k), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
+            gpcc_panel_update<<<cnt8 * (c.nt - k), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, k);
         }
         {
             ProfScope p(h, GPCC_PROF_DIAG, s);
@@ -323,6 +341,10 @@ static int enqueue_group(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, 
             gpcc_panel_trsm<<<cnt8 * (c.nt - k - 1), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
         }
     }
+    // augmented systems: Schur complement of the rows beyond the factorised columns,
+    // S = C - V^T V with V = L^-1 [cross block]  
+    for (int k = c.nt_fact; k < c.nt; ++k)
+        gpcc_panel_update<<<cnt8 * (c.nt - k), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, c.nt_fact);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, GPCC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return 0;
@@ -432,7 +454,7 @@ static int single_eval_export(gpcc_handle_t h, const double *delays, const doubl
     double *d_dense = nullptr;
     const long nn = (long)h->N * h->N;
     HIPCHK(h, hipMalloc(&d_dense, sizeof(double) * nn));
-    gpcc_export_dense<<<(unsigned)((nn + 255) / 256), 256, 0, s>>>(c, 0, d_dense, factor ? 0 : 1);
+    gpcc_export_dense<<<(unsigned)((nn + 255) / 256), 256, 0, s>>>(c, 0, d_dense, factor ? 0 : 1, 0, h->N, 0.0);
     hipError_t e = hipMemcpyAsync(out, d_dense, sizeof(double) * nn, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess && factor && info) e = hipMemcpyAsync(info, h->d_oinfo, sizeof(int), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -450,6 +472,177 @@ extern "C" int gpcc_factor_dense(gpcc_handle_t h, const double *delays, const do
                                  double *L_out, int *info)
 {
     return single_eval_export(h, delays, alpha, rho, L_out, info, true);
+}
+
+// ------------------------------------------------------------------------------------------
+// Augmented systems (prediction, posterior of the offsets).  The points of the handle are followed,
+// from the next tile boundary on, by `next` extra rows (test points, or explicit rows Q / Y); only
+// the first nt (training) tile columns are factorised.  What the unchanged kernels then leave behind:
+//   tiles (extra, extra) = C - V^T V  (V = L^-1 [cross block]): the predictive covariance, resp.
+//                          -R^T K^-1 R for explicit rows R;
+//   z[extra]             = -V^T w = -(kB*)^T K^-1 (Y - bbar): minus the centred predictive mean.
+// One temporary slot; not a hot path.
+// ------------------------------------------------------------------------------------------
+struct AugRun {
+    GpccCtx c;
+    double *d_pts = nullptr;   // t | sig2 | resid | yv (4 x Npa)
+    int *d_band = nullptr;
+    double *d_ws = nullptr;    // tiles | linv | z | w | logdet | quad
+    int *d_info = nullptr;
+    int off = 0, next = 0;
+    void release() { hipFree(d_pts); hipFree(d_band); hipFree(d_ws); hipFree(d_info); d_pts = d_ws = nullptr; d_band = d_info = nullptr; }
+};
+
+static int run_augmented(gpcc_handle_t h, const double *delays, const double *alpha, double rho, int next,
+                         const double *ext_t, const int *ext_band, int marginalise_b, AugRun &a)
+{
+    int rc = set_device(h, h->device);
+    if (rc) return rc;
+    rc = ensure_workspace(h);   // streams + kernel attributes
+    if (rc) return rc;
+    rc = ensure_staging(h, 1);
+    if (rc) return rc;
+    for (int l = 0; l < h->L; ++l)
+        if (!(alpha[l] > 0.0)) return fail(h, GPCC_ERR_ARGUMENT, "AssertionError: all(scale .> 0)");
+    if (rho <= 0.0) return fail(h, GPCC_ERR_ARGUMENT, "ρ=%.8f is <= 0", rho);
+    const int off = h->Np;                                   // extra rows start on a tile boundary
+    const int nta = h->nt + (next + GPCC_TILE - 1) / GPCC_TILE;
+    const int Npa = nta * GPCC_TILE;
+    std::vector<double> pts(4 * (size_t)Npa, 0.0);
+    std::vector<int> band(Npa, -1);
+    for (int i = 0; i < h->N; ++i) {
+        pts[i] = h->t_host[i];
+        pts[Npa + i] = h->sig2_host[i];
+        pts[2 * (size_t)Npa + i] = h->resid_host[i];
+        pts[3 * (size_t)Npa + i] = h->y_host[i];
+        band[i] = h->band_host[i];
+    }
+    for (int i = 0; i < next; ++i) {
+        pts[off + i] = ext_t ? ext_t[i] : 0.0;               // sig2 = 0, resid = 0 for extra rows
+        band[off + i] = ext_band[i];
+    }
+    const long stride = ((long)nta * (nta + 1) / 2) * GPCC_TILE_ELEMS;
+    const size_t wsz = (size_t)stride + GPCC_TILE_ELEMS + 2 * (size_t)Npa + 2;
+    HIPCHK(h, hipMalloc(&a.d_pts, sizeof(double) * pts.size()));
+    hipError_t e = hipMalloc(&a.d_band, sizeof(int) * Npa);
+    if (e == hipSuccess) e = hipMalloc(&a.d_ws, sizeof(double) * wsz);
+    if (e == hipSuccess) e = hipMalloc(&a.d_info, sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(a.d_pts, pts.data(), sizeof(double) * pts.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(a.d_band, band.data(), sizeof(int) * Npa, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { a.release(); return fail(h, GPCC_ERR_HIP, "augmented run: %s", hipGetErrorString(e)); }
+    GpccCtx c = make_ctx(h);
+    c.t = a.d_pts; c.sig2 = a.d_pts + Npa; c.resid = a.d_pts + 2 * (size_t)Npa; c.yv = a.d_pts + 3 * (size_t)Npa;
+    c.band = a.d_band;
+    c.tiles = a.d_ws; c.linv = a.d_ws + stride; c.z = c.linv + GPCC_TILE_ELEMS; c.w = c.z + Npa;
+    c.logdet = c.w + Npa; c.quad = c.logdet + 1; c.info = a.d_info;
+    c.slot_stride = stride; c.Np = Npa; c.nt = nta; c.nt_fact = h->nt; c.marginalise_b = marginalise_b;
+    if (!marginalise_b) for (int l = 0; l < GPCC_MAXL; ++l) c.sigma_b[l] = 0.0;
+    hipStream_t s = h->str[0];
+    double *dd = h->d_par, *da = h->d_par + h->L, *dr = h->d_par + 2 * h->L;
+    e = hipMemcpyAsync(dd, delays, sizeof(double) * h->L, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(da, alpha, sizeof(double) * h->L, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dr, &rho, sizeof(double), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) { a.release(); return fail(h, GPCC_ERR_HIP, "augmented run: %s", hipGetErrorString(e)); }
+    GpccGroup g;
+    g.delays = dd; g.alpha = da; g.rho = dr; g.out_loglik = h->d_out; g.out_info = h->d_oinfo;
+    g.first = 0; g.slot0 = 0; g.cnt = 1;
+    const bool was_prof = h->prof;
+    h->prof = false;
+    rc = enqueue_group(h, c, g, s, true, true);
+    h->prof = was_prof;
+    if (rc) { a.release(); return rc; }
+    a.c = c; a.off = off; a.next = next;
+    return 0;
+}
+
+// copies the (extra x extra) block (symmetric, + jitter on the diagonal), z[extra], loglik and info back
+static int fetch_augmented(gpcc_handle_t h, AugRun &a, double *block, double *zext, double *loglik, int *info, double jitter)
+{
+    hipStream_t s = h->str[0];
+    const long nn = (long)a.next * a.next;
+    double *d_dense = nullptr;
+    hipError_t e = hipMalloc(&d_dense, sizeof(double) * nn);
+    if (e == hipSuccess) {
+        gpcc_export_dense<<<(unsigned)((nn + 255) / 256), 256, 0, s>>>(a.c, 0, d_dense, 1, a.off, a.next, jitter);
+        e = hipMemcpyAsync(block, d_dense, sizeof(double) * nn, hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess && zext) e = hipMemcpyAsync(zext, a.c.z + a.off, sizeof(double) * a.next, hipMemcpyDeviceToHost, s);
+    double ll = 0.0;
+    int inf = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&ll, h->d_out, sizeof(double), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&inf, h->d_oinfo, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    hipFree(d_dense);
+    a.release();
+    if (e != hipSuccess) return fail(h, GPCC_ERR_HIP, "augmented fetch: %s", hipGetErrorString(e));
+    if (loglik) *loglik = ll;
+    if (info) *info = inf;
+    return 0;
+}
+
+extern "C" int gpcc_predict(gpcc_handle_t h, const double *delays, const double *alpha, double rho, const int *Ntest,
+                            const double *ttest, double *mu_out, double *Sigma_out, double *loglik, int *info)
+{
+    if (!h || !delays || !alpha || !Ntest || !ttest || !mu_out || !Sigma_out) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
+    long nt = 0;
+    for (int l = 0; l < h->L; ++l) { if (Ntest[l] < 0) return fail(h, GPCC_ERR_ARGUMENT, "negative Ntest"); nt += Ntest[l]; }
+    if (nt <= 0 || nt > 32768) return fail(h, GPCC_ERR_ARGUMENT, "total number of test points %ld outside [1, 32768]", nt);
+    std::vector<int> eb(nt);
+    long o = 0;
+    for (int l = 0; l < h->L; ++l) for (int n = 0; n < Ntest[l]; ++n) eb[o++] = l;
+    AugRun a;
+    int rc = run_augmented(h, delays, alpha, rho, (int)nt, ttest, eb.data(), h->mb, a);
+    if (rc) return rc;
+    std::vector<double> z(nt);
+    // Σpred = cB - kB*' (KSobsB \ kB*) + JITTER*I  (marginaliseb.jl:275-279), JITTER = 1e-8 (:69)
+    rc = fetch_augmented(h, a, Sigma_out, z.data(), loglik, info, 1e-8);
+    if (rc) return rc;
+    // μpred = kB*' (KSobsB \ (Y - b̄)) + Q* μb  (:283-285);  z[test] = -(kB*)' K^-1 (Y - b̄)
+    for (long i = 0; i < nt; ++i) mu_out[i] = -z[i] + h->mean_b[eb[i]];
+    return 0;
+}
+
+extern "C" int gpcc_posterior_offsets(gpcc_handle_t h, const double *delays, const double *alpha, double rho,
+                                      double *mu_postb, double *Sigma_postb, int *info)
+{
+    if (!h || !delays || !alpha || !mu_postb || !Sigma_postb) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
+    if (!h->mb) return fail(h, GPCC_ERR_ARGUMENT, "the fixed-b variant (gpccfixdelay.jl) has no posterior over offsets");
+    const int L = h->L, ne = L + 1;
+    std::vector<int> eb(ne);
+    for (int e = 0; e < ne; ++e) eb[e] = -2 - e;          // rows Q[:,0..L-1] and Y against (Sobs + K), no B term
+    AugRun a;
+    int rc = run_augmented(h, delays, alpha, rho, ne, nullptr, eb.data(), 0, a);
+    if (rc) return rc;
+    std::vector<double> S((size_t)ne * ne);
+    int inf = 0;
+    rc = fetch_augmented(h, a, S.data(), nullptr, nullptr, &inf, 0.0);
+    if (rc) return rc;
+    if (info) *info = inf;
+    // S = -[Q Y]' (Sobs+K)^-1 [Q Y].   Σpostb = (Σb^-1 + Q'(Sobs+K)^-1 Q)^-1 ;
+    // μpostb = Σpostb (Q'(Sobs+K)^-1 Y + Σb^-1 μb)      (marginaliseb.jl:248-250)
+    std::vector<double> A((size_t)L * 2 * L, 0.0);        // [Σb^-1 + Q'K^-1Q | I] -> Gauss-Jordan
+    for (int i = 0; i < L; ++i) {
+        for (int j = 0; j < L; ++j) A[i * 2 * L + j] = -S[(size_t)j * ne + i] + (i == j ? 1.0 / h->sigma_b[i] : 0.0);
+        A[i * 2 * L + L + i] = 1.0;
+    }
+    for (int p = 0; p < L; ++p) {                          // SPD: no pivoting needed
+        const double piv = A[p * 2 * L + p];
+        for (int j = 0; j < 2 * L; ++j) A[p * 2 * L + j] /= piv;
+        for (int i = 0; i < L; ++i) {
+            if (i == p) continue;
+            const double f = A[i * 2 * L + p];
+            for (int j = 0; j < 2 * L; ++j) A[i * 2 * L + j] -= f * A[p * 2 * L + j];
+        }
+    }
+    for (int i = 0; i < L; ++i)
+        for (int j = 0; j < L; ++j)
+            Sigma_postb[(size_t)j * L + i] = 0.5 * (A[i * 2 * L + L + j] + A[j * 2 * L + L + i]);   // makematrixsymmetric, :252
+    for (int i = 0; i < L; ++i) {
+        double acc = 0.0;
+        for (int j = 0; j < L; ++j) acc += A[i * 2 * L + L + j] * (-S[(size_t)j * ne + L] + h->mean_b[j] / h->sigma_b[j]);
+        mu_postb[i] = acc;
+    }
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------

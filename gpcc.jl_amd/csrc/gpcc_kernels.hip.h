@@ -36,10 +36,14 @@ struct GpccCtx {
     double *quad;    // slots         : |w|^2
     int *info;       // slots
     const double *t, *sig2, *resid;  // Np (padding: 0)
-    const int *band;                 // Np (padding: -1)
+    const double *yv;                // Np: raw fluxes (only read by explicit 'Y' rows, see band codes)
+    const int *band;                 // Np: >= 0 band of a real point; -1 identity padding;
+                                     // <= -2 explicit row e = -2-code: e < L: indicator of band e (a column of Q),
+                                     // e == L: the flux vector Y  (rows of the augmented systems)
     double sigma_b[GPCC_MAXL];
     long slot_stride;
     int L, N, Np, nt, kernel_id, marginalise_b;
+    int nt_fact;  // tile columns that are factorised (== nt for the plain log-likelihood)
 };
 
 struct GpccGroup {
@@ -141,7 +145,7 @@ __device__ __forceinline__ double gpcc_kernel_eval(double xi, double xj, GpccKer
 // a no-op, K is exactly symmetric, so only the lower triangle is materialised).
 // grid (nt*nt, cnt), block 256.
 // ------------------------------------------------------------------------------------------
-template <int KID>
+template <int KID, bool EXT>
 __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup g)
 {
     const int I = blockIdx.x / c.nt, J = blockIdx.x % c.nt;
@@ -154,6 +158,7 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
 
     __shared__ __attribute__((aligned(16))) double su[2][GPCC_TILE], sa[2][GPCC_TILE], ssig[GPCC_TILE], ssb[GPCC_MAXL];
     __shared__ int sb[2][GPCC_TILE];
+    __shared__ double syv[EXT ? GPCC_TILE : 1];   // fluxes of the tile's columns (explicit 'Y' rows only)
     if (tid < GPCC_MAXL) ssb[tid] = (tid < c.L) ? c.sigma_b[tid] : 0.0;
 
     if (I == 0 && tid == 0) {  // per-slot state + the reference's argument checks
@@ -175,6 +180,8 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
         if (side == 0) {
             ssig[r] = c.sig2[gi];
             if (I == J) c.z[(long)slot * c.Np + gi] = c.resid[gi];  // z <- Y - bbar
+        } else if (EXT) {
+            syv[r] = c.yv[gi];
         }
     }
     __syncthreads();
@@ -206,6 +213,14 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
                 if (diag && r == cc) val = val + sg;                       // + Sobs
                 if (br == bc) val = val + bterm;                           // + B = Q Sigma_b Q'
                 if (br < 0 || bc < 0) val = (diag && r == cc) ? 1.0 : 0.0;  // identity padding
+                if (EXT) {  // explicit rows of an augmented system against real columns; 0 among themselves
+                    if (br <= -2) {
+                        const int e = -2 - br;
+                        val = (bc >= 0) ? ((e < c.L) ? ((bc == e) ? 1.0 : 0.0) : syv[cc]) : 0.0;
+                    } else if (bc <= -2) {
+                        val = 0.0;  // never read: explicit points come last, so they are rows of the lower triangle
+                    }
+                }
                 v[h] = val;
             }
             *(d2 *)(T + ch * GPCC_CHUNK + r * GPCC_KC + sp * 2) = v;
@@ -254,7 +269,7 @@ __device__ __forceinline__ void gpcc_load_frag(const double *chunk, int row, int
 // Blocks of one evaluation share blockIdx % 8, i.e. (as dispatched) an XCD and its L2: they all
 // stream tile row k.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup g, int k)
+__global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup g, int k, int ktiles)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -273,7 +288,7 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
     const double *gA = tiles + gpcc_tile_off(I, 0);
     const double *gB = tiles + gpcc_tile_off(k, 0);
     double *T = tiles + gpcc_tile_off(I, k);
-    const int nch = 8 * k;
+    const int nch = 8 * ktiles;  // ktiles = k, or nt_fact for the Schur-complement tiles beyond the factorised columns
 
     gpcc_dma_chunk(gA, gB, smem, wave, lane);
 
@@ -450,7 +465,7 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, q = lane >> 4;
     const int m = blockIdx.x, slot = g.slot0 + m;
-    const bool last = (k == c.nt - 1);
+    const bool last = (k == c.nt_fact - 1);
     const int inf = c.info[slot];
     if (inf != 0) {
         if (last && tid == 0) {
@@ -612,18 +627,19 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
 // ------------------------------------------------------------------------------------------
 // dense exports (tests, prediction): tiles of one slot -> column-major N x N
 // ------------------------------------------------------------------------------------------
-__global__ void gpcc_export_dense(GpccCtx c, int slot, double *out, int symmetric)
+__global__ void gpcc_export_dense(GpccCtx c, int slot, double *out, int symmetric, int off, int n, double jitter)
 {
-    const long n = c.N;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n * n) return;
-    const int r = (int)(idx % n), col = (int)(idx / n);
+    if (idx >= (long)n * n) return;
+    const int r0 = (int)(idx % n), c0 = (int)(idx / n);
+    const int r = off + r0, col = off + c0;
     const double *tiles = c.tiles + (long)slot * c.slot_stride;
     double v;
     if (r >= col)
         v = tiles[gpcc_tile_off(r >> 7, col >> 7) + gpcc_elem_off(r & 127, col & 127)];
     else
         v = symmetric ? tiles[gpcc_tile_off(col >> 7, r >> 7) + gpcc_elem_off(col & 127, r & 127)] : 0.0;
+    if (r0 == c0) v += jitter;
     out[idx] = v;
 }
 

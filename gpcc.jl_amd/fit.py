@@ -1,0 +1,103 @@
+"""gpcc(): the per-delay model fit of the reference (src/gpccfixdelay_marginaliseb.jl:46-53, :56-352),
+host logic in Python over the device objective.  A whole grid of candidate delays is fitted in
+lock-step (neldermead.BatchedNelderMead): every optimiser round is ONE gpcc_loglik_batch call.
+
+Restated from the reference: parameter packing `unpack` (:112-126), initial rho values (:160-176),
+`sampleα` (:188), `sampleunconstrainedsolution` (:195-196), `getsolution` (:203-215: the best of
+`initialrandom` random candidates starts Nelder-Mead), restarts (:222-226), returned value
+`-result.minimum` (:351).
+
+Not reproducible here (no Julia): MersenneTwister's stream (numpy's PCG64 is used; like the reference,
+every delay of a grid sees the SAME random draws because each gpcc call seeds its own generator with
+`seed`), Optim's exact trajectory, and MiscUtil's transforms, whose source is not under
+/root/reference: `makepositive` is taken to be softplus and `transformbetween(x, a, b)` to be
+a + (b - a) * logistic(x), the package's documented purpose; `safewrapper` is taken to turn exceptions
+(PosDefException) into +Inf of the negative objective."""
+import numpy as np
+
+from .api import Objective
+from .neldermead import BatchedNelderMead
+
+
+def makepositive(x):
+    x = np.asarray(x, dtype=np.float64)
+    return np.where(x > 30.0, x, np.log1p(np.exp(np.minimum(x, 30.0))))
+
+
+def invmakepositive(y):
+    y = np.asarray(y, dtype=np.float64)
+    return np.where(y > 30.0, y, np.log(np.expm1(np.minimum(y, 30.0))))
+
+
+def transformbetween(x, a, b):
+    x = np.asarray(x, dtype=np.float64)
+    return a + (b - a) / (1.0 + np.exp(-x))
+
+
+def invtransformbetween(y, a, b):
+    u = (np.asarray(y, dtype=np.float64) - a) / (b - a)
+    return np.log(u) - np.log1p(-u)
+
+
+def logrange(a, b, n):
+    return np.exp(np.linspace(np.log(a), np.log(b), n))
+
+
+class GridFit:
+    """Result of gpcc_grid: loglikel[G] (= -minimum, what README.md:172-174 feeds to
+    getprobabilities), alpha[G, L], rho[G], f_calls, rounds."""
+
+    def __init__(self, loglikel, alpha, rho, f_calls, rounds, iterations_done):
+        self.loglikel, self.alpha, self.rho = loglikel, alpha, rho
+        self.f_calls, self.rounds, self.iterations_done = f_calls, rounds, iterations_done
+
+
+def gpcc_grid(tarray, yarray, stdarray, *, kernel, candidatedelays, iterations, seed=1, numberofrestarts=1,
+              initialrandom=5, rhomin=0.1, rhomax=20.0, objective=None, device=0, marginalise_b=True):
+    """Fits the GPCC model for each row of candidatedelays (G, L): the README's
+    `map(delay -> gpcc(...; delays = [0; delay])[1], candidatedelays)` as one lock-step batch."""
+    cand = np.ascontiguousarray(np.atleast_2d(candidatedelays), dtype=np.float64)
+    G, L = cand.shape
+    assert L == len(tarray) == len(yarray) == len(stdarray)          # marginaliseb.jl:78
+    own = objective is None
+    obj = objective if objective is not None else Objective(tarray, yarray, stdarray, kernel,
+                                                            marginalise_b=marginalise_b, device=device)
+    try:
+        R = int(numberofrestarts)
+        rg = np.random.default_rng(seed)
+        if R in (1, 2):                                                  # :160-176
+            rho0 = rg.uniform(rhomin + 1e-3, rhomax - 1e-3, R)
+        else:
+            rho0 = logrange(rhomin + 1e-3, rhomax - 1e-3, R)
+        vary = np.array([np.var(np.asarray(y, dtype=np.float64), ddof=1) for y in yarray])
+        # the same candidates for every delay (each reference call re-seeds): (R, initialrandom, L+1)
+        cands = np.empty((R, initialrandom, L + 1))
+        for i in range(R):
+            for c in range(initialrandom):
+                cands[i, c, :L] = invmakepositive(vary * (rg.random(L) * (1.2 - 0.8) + 0.8))   # sampleα, :188
+                cands[i, c, L] = invtransformbetween(rho0[i], rhomin, rhomax)
+        P = G * R                                                        # problem p = (delay p // R, restart p % R)
+
+        def negobj(pidx, X):
+            alpha = makepositive(X[:, :L]) + 1e-8                        # makeα, :112
+            rho = transformbetween(X[:, L], rhomin, rhomax)              # makeρ, :114
+            ll, info = obj.loglik_batch(cand[pidx // R], alpha, rho)
+            return np.where(info == 0, -ll, np.inf)                      # safewrapper(negativeobjective), :149-153
+
+        # argmin over the random candidates (:209)
+        pid = np.repeat(np.arange(P), initialrandom)
+        Xc = cands[np.tile(np.repeat(np.arange(R), initialrandom), G), np.tile(np.arange(initialrandom), P)]
+        f0 = negobj(pid, Xc).reshape(P, initialrandom)
+        best = np.argmin(f0, axis=1)
+        x0 = Xc.reshape(P, initialrandom, L + 1)[np.arange(P), best]
+        nm = BatchedNelderMead(x0, negobj, iterations=iterations, g_tol=1e-6)   # Optim.Options(g_tol = 1e-6), :205
+        xmin, fmin = nm.run()
+        fmin = fmin.reshape(G, R)
+        pick = np.argmin(fmin, axis=1)                                   # best restart, :224
+        xsel = xmin.reshape(G, R, L + 1)[np.arange(G), pick]
+        return GridFit(-fmin[np.arange(G), pick], makepositive(xsel[:, :L]) + 1e-8,
+                       transformbetween(xsel[:, L], rhomin, rhomax), nm.f_calls + P * initialrandom, nm.rounds + 1,
+                       nm.iterations_done.reshape(G, R)[np.arange(G), pick])
+    finally:
+        if own:
+            obj.close()

@@ -90,6 +90,20 @@ int gpcc_model_matrix(gpcc_handle_t handle, const double *delays, const double *
 int gpcc_factor_dense(gpcc_handle_t handle, const double *delays, const double *alpha, double rho,
                       double *L_out, int *info);
 
+/* predictTest(ttest::Vector{Vector}) of src/gpccfixdelay_marginaliseb.jl:259-289 at given (tau, alpha, rho):
+ * joint predictive mean mu_out[sum Ntest] and covariance Sigma_out (column-major, + JITTER*I, :279) for
+ * Ntest[l] test times per band (flattened in band order); also the training log-likelihood / info.
+ * One augmented factorisation on the device: Sigma = cB - V'V, mu = V'w + Q* mu_b with V = L^-1 kB*. */
+int gpcc_predict(gpcc_handle_t handle, const double *delays, const double *alpha, double rho,
+                 const int *Ntest, const double *ttest, double *mu_out, double *Sigma_out,
+                 double *loglik, int *info);
+
+/* Posterior of the offsets b (src/gpccfixdelay_marginaliseb.jl:248-252): mu_postb[L], Sigma_postb[L x L]
+ * (column-major, symmetrised).  The N x N solves (Sobs + K) \ [Q Y] run on the device as an augmented
+ * factorisation; only the final L x L inverse is host arithmetic. */
+int gpcc_posterior_offsets(gpcc_handle_t handle, const double *delays, const double *alpha, double rho,
+                           double *mu_postb, double *Sigma_postb, int *info);
+
 /* delayedCovariance(kernel, scale, delays, rho, x, y) of src/delayedCovariance.jl:1-35 (pass
  * y == x, Ny == Nx for the 5-argument form, :38).  out is column-major (sum Nx) x (sum Ny).
  * Returns GPCC_ERR_ARGUMENT with the reference's message for scale <= 0 / rho <= 0. */

@@ -1,0 +1,54 @@
+"""Host logic of gpcc_grid (lock-step fit over a delay grid) with the CPU oracle injected as the
+objective (tests may use the oracle; the product path uses gpcc_amd.Objective = the HIP library)."""
+import numpy as np
+
+from gpcc_amd import fit, synthetic
+
+
+class OracleObjective:
+    """Stand-in with Objective's loglik_batch signature."""
+
+    def __init__(self, oracle, kernel, t, y, s):
+        self.o, self.k, self.t, self.y, self.s = oracle, kernel, t, y, s
+        self.calls = 0
+
+    def loglik_batch(self, delays, alpha, rho):
+        self.calls += 1
+        return self.o.loglik_batch(self.k, self.t, self.y, self.s, delays, alpha, rho, True, nthreads=8)
+
+
+def test_transforms_roundtrip():
+    x = np.linspace(-20, 40, 13)
+    assert np.allclose(fit.invmakepositive(fit.makepositive(x)), x, atol=1e-9)
+    r = fit.transformbetween(x, 0.1, 20.0)
+    assert np.all((r >= 0.1) & (r <= 20.0)) and np.allclose(fit.invtransformbetween(r[3:9], 0.1, 20.0), x[3:9])
+    assert np.allclose(fit.logrange(0.101, 19.999, 4)[[0, -1]], [0.101, 19.999])
+
+
+def test_gpcc_grid_lockstep_equals_single_delay_runs(oracle):
+    t, y, s, _ = synthetic.simulate_lightcurves([40, 30], seed=5, span=20.0)
+    cand = np.stack([np.zeros(4), np.array([0.5, 2.0, 3.5, 9.0])], 1)
+    obj = OracleObjective(oracle, "matern32", t, y, s)
+    res = fit.gpcc_grid(t, y, s, kernel="matern32", candidatedelays=cand, iterations=40, rhomax=20.0, objective=obj)
+    assert res.loglikel.shape == (4,) and res.alpha.shape == (4, 2) and np.all(res.alpha > 0)
+    assert np.all((res.rho > 0.1) & (res.rho < 20.0)) and obj.calls == res.rounds
+    for g in range(4):   # every delay follows the trajectory it follows alone (same seed => same start)
+        one = fit.gpcc_grid(t, y, s, kernel="matern32", candidatedelays=cand[[g]], iterations=40, rhomax=20.0,
+                            objective=OracleObjective(oracle, "matern32", t, y, s))
+        assert one.loglikel[0] == res.loglikel[g] and np.array_equal(one.alpha[0], res.alpha[g])
+    # the optimiser improves on the best random start and the returned value is objective(alpha, rho)
+    ll, info = oracle.loglik_batch("matern32", t, y, s, cand, res.alpha, res.rho, True)
+    assert np.allclose(ll, res.loglikel, rtol=1e-12)
+
+
+def test_gpcc_grid_restarts_and_posterior_mode(oracle):
+    t, y, s, _ = synthetic.simulate_lightcurves([60, 50], seed=1, gap_band=1, span=20.0)
+    grid = np.arange(0.0, 8.01, 1.0)
+    cand = np.stack([np.zeros_like(grid), grid], 1)
+    obj = OracleObjective(oracle, "OU", t, y, s)
+    r1 = fit.gpcc_grid(t, y, s, kernel="OU", candidatedelays=cand, iterations=120, rhomax=20.0, objective=obj)
+    r3 = fit.gpcc_grid(t, y, s, kernel="OU", candidatedelays=cand, iterations=120, rhomax=20.0, objective=obj,
+                       numberofrestarts=3)
+    assert np.all(r3.loglikel >= r1.loglikel - 2.0)    # more restarts do not make the fit much worse
+    p = oracle.probabilities(r3.loglikel)
+    assert abs(grid[np.argmax(p)] - 2.0) <= 1.0          # true delay 2.0 (README.md:156-179, qualitative)

@@ -229,3 +229,65 @@ def test_cfg4_three_band_2d_grid(gp, oracle):
     assert (rinfo == 0).all() and _rel(ll[[4, 29]], ref) <= LL_RTOL
     post = gp.getprobabilities(ll.reshape(6, 6))
     assert post.shape == (6, 6) and abs(post.sum() - 1) < 1e-12
+
+
+# ---- section 8(f) rows: predictTest and the posterior of the offsets ----------------------------------------
+def _reference_predict(oracle, kname, t, y, s, delays, alpha, rho, ttest):
+    """marginaliseb.jl:259-289 restated with the oracle's matrices and numpy solves (test-side)."""
+    L = len(t)
+    K, resid = oracle.model_matrix(kname, t, y, s, delays, alpha, rho, True)            # KSobsB, Y - bbar
+    mub = np.array([np.mean(a) for a in y])
+    Sigb = 100 * np.array([np.var(a, ddof=1) for a in y])
+    bt = np.concatenate([np.full(len(a), l) for l, a in enumerate(t)])
+    bs = np.concatenate([np.full(len(a), l) for l, a in enumerate(ttest)])
+    kB = oracle.delayed_covariance(kname, alpha, delays, rho, t, ttest) + (bt[:, None] == bs[None, :]) * Sigb[bt][:, None]
+    cB = oracle.delayed_covariance(kname, alpha, delays, rho, ttest) + (bs[:, None] == bs[None, :]) * Sigb[bs][:, None]
+    Sig = cB - kB.T @ np.linalg.solve(K, kB)
+    Sig = (Sig + Sig.T) / 2 + 1e-8 * np.eye(len(bs))
+    mu = kB.T @ np.linalg.solve(K, resid) + mub[bs]
+    return mu, Sig
+
+
+@pytest.mark.parametrize("shape", [([60, 50], [40, 40]), ([150, 140, 130], [30, 0, 45]), ([700, 650], [200, 150])])
+def test_predict_vs_reference_formulas(gp, oracle, shape):
+    from gpcc_amd import synthetic
+    Nl, Nt = shape
+    t, y, s, _ = synthetic.simulate_lightcurves(Nl, seed=4)
+    L = len(Nl)
+    delays = [0.0, 2.0, 4.0][:L]
+    alpha = [1.0, 1.4, 0.8][:L]
+    rho = 3.1
+    rng = np.random.default_rng(1)
+    span = max(float(np.max(a)) for a in t)
+    ttest = [np.sort(rng.random(n) * (span + 10) - 5) for n in Nt]
+    with gp.Objective(t, y, s, gp.matern32) as obj:
+        mu, Sig = obj.predict(delays, alpha, rho, ttest)
+        mu2, Sig2 = obj.predict(delays, alpha, rho, ttest)          # repeatable
+    assert np.array_equal(mu, mu2) and np.array_equal(Sig, Sig2)
+    mu_ref, Sig_ref = _reference_predict(oracle, "matern32", t, y, s, delays, alpha, rho, ttest)
+    scale = np.max(np.abs(Sig_ref))
+    assert np.max(np.abs(mu - mu_ref)) <= 1e-8 * np.max(np.abs(mu_ref))
+    assert np.max(np.abs(Sig - Sig_ref)) <= 1e-8 * scale
+    assert np.array_equal(Sig, Sig.T)
+
+
+def test_posterior_offsets_vs_reference_formulas(gp, oracle):
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([300, 260, 220], seed=6)
+    delays, alpha, rho = [0.0, 2.0, 4.0], [1.0, 2.1, 3.7], 3.5
+    with gp.Objective(t, y, s, gp.OU) as obj:
+        mu, Sig = obj.posterior_offsets(delays, alpha, rho)
+    K0, _ = oracle.model_matrix("OU", t, y, s, delays, alpha, rho, False)          # Sobs + K (no B)
+    Nl = [len(a) for a in t]
+    Q = np.zeros((sum(Nl), 3))
+    o = 0
+    for l, n in enumerate(Nl):
+        Q[o:o + n, l] = 1
+        o += n
+    Y = np.concatenate(y)
+    Sigb = np.diag(100 * np.array([np.var(a, ddof=1) for a in y]))
+    mub = np.array([np.mean(a) for a in y])
+    Sref = np.linalg.inv(np.linalg.inv(Sigb) + Q.T @ np.linalg.solve(K0, Q))       # marginaliseb.jl:248
+    mref = Sref @ (Q.T @ np.linalg.solve(K0, Y) + np.linalg.solve(Sigb, mub))       # :250
+    np.testing.assert_allclose(Sig, Sref, rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(mu, mref, rtol=1e-7)
