@@ -36,6 +36,8 @@ SIGNATURES = {
                                     c_double_p, c_double_p, c_double_p, c_int_p]),
     "gpcc_posterior_offsets": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, ctypes.c_double, c_double_p,
                                               c_double_p, c_int_p]),
+    "gpcc_mvnormal_logpdf": (ctypes.c_int, [ctypes.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_int_p,
+                                            ctypes.c_int]),
     "gpcc_covariance": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, ctypes.c_double, c_int_p,
                                        c_double_p, c_int_p, c_double_p, c_double_p, ctypes.c_int]),
     "gpcc_probabilities": (ctypes.c_int, [ctypes.c_int, c_double_p, c_double_p, c_double_p, ctypes.c_int]),

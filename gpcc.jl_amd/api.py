@@ -120,6 +120,21 @@ def getprobabilities(loglikel, logpriorpdfvalues=None, device=0):
     return out.reshape(shape)
 
 
+def mvnormal_logpdf(mu, Sigma, x, device=0):
+    """logpdf(MvNormal(mu, Sigma), x) with an explicit covariance, on the device (marginaliseb.jl:325);
+    raises PosDefException when the Cholesky factorisation fails."""
+    Sigma = np.ascontiguousarray(np.asarray(Sigma, dtype=np.float64).T)   # column-major for the ABI
+    n = Sigma.shape[0]
+    mu, x = _d(mu), _d(x)
+    assert Sigma.shape == (n, n) and mu.shape == (n,) and x.shape == (n,)
+    ll, info = ctypes.c_double(0.0), ctypes.c_int(0)
+    _capi.check(_capi.load().gpcc_mvnormal_logpdf(n, _dp(Sigma), _dp(mu), _dp(x), ctypes.byref(ll), ctypes.byref(info),
+                                                  int(device)))
+    if info.value > 0:
+        raise PosDefException(info.value)
+    return ll.value
+
+
 class Objective:
     """The marginal log-likelihood objective(alpha, rho) of gpccfixdelay, bound to one data set and
     living on one GPU.  The delay vector is an argument (the reference captures tau in the

@@ -247,6 +247,16 @@ extern "C" int gpcc_get_constants(gpcc_handle_t h, double *mean_b, double *Sigma
     return 0;
 }
 
+// the diagonal kernel needs 149 KiB of dynamic LDS, the MFMA kernels 64 KiB (per device, idempotent)
+static int set_kernel_attributes(gpcc_handle_t h)
+{
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_diag_factor, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  GPCC_DIAG_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 static int ensure_workspace(gpcc_handle_t h)
 {
@@ -266,10 +276,7 @@ static int ensure_workspace(gpcc_handle_t h)
         HIPCHK(h, hipStreamCreateWithFlags(&h->str[s], hipStreamNonBlocking));
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_done[s], hipEventDisableTiming));
     }
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_diag_factor, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  GPCC_DIAG_LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    { int rc_ = set_kernel_attributes(h); if (rc_) return rc_; }
     h->ws_streams = h->streams;
     h->ws_slots = h->slots_per_stream;
     h->ws_ready = true;
@@ -321,11 +328,19 @@ static void launch_assemble(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &
 }
 
 // assemble + left-looking blocked Cholesky + fused forward solve for one group on stream s
+static int enqueue_factor(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s);
+
 static int enqueue_group(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s, bool factor = true,
                          bool ext = false)
 {
     launch_assemble(h, c, g, s, ext);
     if (!factor) return 0;
+    return enqueue_factor(h, c, g, s);
+}
+
+// left-looking blocked Cholesky + fused forward solve (+ Schur complement of non-factorised rows)
+static int enqueue_factor(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s)
+{
     const int cnt8 = 8 * ((g.cnt + 7) / 8);
     for (int k = 0; k < c.nt_fact; ++k) {
         if (k > 0) {
@@ -642,6 +657,50 @@ extern "C" int gpcc_posterior_offsets(gpcc_handle_t h, const double *delays, con
         for (int j = 0; j < L; ++j) acc += A[i * 2 * L + L + j] * (-S[(size_t)j * ne + L] + h->mean_b[j] / h->sigma_b[j]);
         mu_postb[i] = acc;
     }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int gpcc_mvnormal_logpdf(int n, const double *Sigma, const double *mu, const double *x, double *loglik,
+                                    int *info, int device_id)
+{
+    if (n < 1 || n > 65536 || !Sigma || !x || !loglik || !info) return fail(nullptr, GPCC_ERR_ARGUMENT, "bad argument");
+    int rc = set_device(nullptr, device_id);
+    if (rc) return rc;
+    gpcc_handle_s tmp;   // stack handle: only err/prof fields are touched by the helpers
+    rc = set_kernel_attributes(&tmp);
+    if (rc) return fail(nullptr, rc, "%s", tmp.err.c_str());
+    const int nt = (n + GPCC_TILE - 1) / GPCC_TILE, Np = nt * GPCC_TILE;
+    const long stride = ((long)nt * (nt + 1) / 2) * GPCC_TILE_ELEMS;
+    const size_t wsz = (size_t)stride + GPCC_TILE_ELEMS + 2 * (size_t)Np + 4;
+    std::vector<double> r(n);
+    for (int i = 0; i < n; ++i) r[i] = x[i] - (mu ? mu[i] : 0.0);
+    double *d_ws = nullptr, *d_in = nullptr;
+    int *d_info = nullptr;
+    hipError_t e = hipMalloc(&d_ws, sizeof(double) * wsz);
+    if (e == hipSuccess) e = hipMalloc(&d_in, sizeof(double) * ((size_t)n * n + n));
+    if (e == hipSuccess) e = hipMalloc(&d_info, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(d_in, Sigma, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_in + (size_t)n * n, r.data(), sizeof(double) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        GpccCtx c;
+        memset(&c, 0, sizeof c);
+        c.tiles = d_ws; c.linv = d_ws + stride; c.z = c.linv + GPCC_TILE_ELEMS; c.w = c.z + Np;
+        c.logdet = c.w + Np; c.quad = c.logdet + 1; c.info = d_info;
+        c.slot_stride = stride; c.L = 1; c.N = n; c.Np = Np; c.nt = nt; c.nt_fact = nt;
+        GpccGroup g;
+        memset(&g, 0, sizeof g);
+        g.out_loglik = c.quad + 1; g.out_info = d_info + 1; g.cnt = 1;
+        gpcc_load_dense<<<nt * nt, 256>>>(c, 0, d_in, n, d_in + (size_t)n * n);
+        rc = enqueue_factor(&tmp, c, g, nullptr);
+        if (rc == 0) {
+            e = hipMemcpy(loglik, g.out_loglik, sizeof(double), hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(info, g.out_info, sizeof(int), hipMemcpyDeviceToHost);
+        }
+    }
+    hipFree(d_ws); hipFree(d_in); hipFree(d_info);
+    if (rc) return fail(nullptr, rc, "%s", tmp.err.c_str());
+    if (e != hipSuccess) return fail(nullptr, GPCC_ERR_HIP, "gpcc_mvnormal_logpdf: %s", hipGetErrorString(e));
     return 0;
 }
 

@@ -644,6 +644,30 @@ __global__ void gpcc_export_dense(GpccCtx c, int slot, double *out, int symmetri
 }
 
 // ------------------------------------------------------------------------------------------
+// gpcc_load_dense: a caller-supplied symmetric matrix (column-major n x n) into the tile layout of a
+// slot, z <- resid: logpdf(MvNormal(mu, Sigma), x) for an explicit Sigma (the test log-likelihood of
+// predictTest, marginaliseb.jl:311-343) then runs on the same factorisation kernels.
+// grid nt*nt, block 256.
+// ------------------------------------------------------------------------------------------
+__global__ void gpcc_load_dense(GpccCtx c, int slot, const double *dense, int n, const double *resid)
+{
+    const int I = blockIdx.x / c.nt, J = blockIdx.x % c.nt;
+    if (J > I) return;
+    const int tid = threadIdx.x;
+    if (I == 0 && tid == 0) { c.info[slot] = 0; c.logdet[slot] = 0.0; c.quad[slot] = 0.0; }
+    double *T = c.tiles + (long)slot * c.slot_stride + gpcc_tile_off(I, J);
+    for (int e = tid; e < GPCC_TILE_ELEMS; e += 256) {
+        const int r = e & 127, col = e >> 7;   // consecutive threads walk down a column of the dense input
+        const long gr = (long)I * GPCC_TILE + r, gc = (long)J * GPCC_TILE + col;
+        T[gpcc_elem_off(r, col)] = (gr < n && gc < n) ? dense[gc * n + gr] : ((gr == gc) ? 1.0 : 0.0);
+    }
+    if (I == J && tid < GPCC_TILE) {
+        const long gr = (long)I * GPCC_TILE + tid;
+        c.z[(long)slot * c.Np + gr] = (gr < n) ? resid[gr] : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // delayedCovariance(kernel, scale, delays, rho, x, y), rectangular, column-major output
 // (src/delayedCovariance.jl:1-35).  xu/yu arrive already shifted (x - delays[band]).
 // ------------------------------------------------------------------------------------------

@@ -15,7 +15,7 @@ a + (b - a) * logistic(x), the package's documented purpose; `safewrapper` is ta
 (PosDefException) into +Inf of the negative objective."""
 import numpy as np
 
-from .api import Objective
+from .api import Objective, PosDefException, mvnormal_logpdf
 from .neldermead import BatchedNelderMead
 
 
@@ -101,3 +101,53 @@ def gpcc_grid(tarray, yarray, stdarray, *, kernel, candidatedelays, iterations, 
     finally:
         if own:
             obj.close()
+
+
+class Predictor:
+    """The `predictTest` closure returned by gpcc() (marginaliseb.jl:259-343), three call forms:
+      pred(ttest)                       ttest = list of L arrays  -> (mu_pred, Sigma_pred), joint    (:259-289)
+      pred(ttest)                       ttest = one array / range -> (mu per band, sigma per band)   (:293-307)
+      pred(ttest, ytest, sigmatest)     lists of L arrays         -> test log-likelihood             (:311-343)
+    All linear algebra runs on the device (Objective.predict / mvnormal_logpdf)."""
+
+    def __init__(self, objective, delays, alpha, rho):
+        self.obj, self.delays, self.alpha, self.rho = objective, np.array(delays, float), np.array(alpha, float), float(rho)
+
+    def __call__(self, ttest, ytest=None, sigmatest=None):
+        L = self.obj.L
+        joint = isinstance(ttest, (list, tuple)) and len(ttest) == L and all(np.ndim(a) == 1 for a in ttest)
+        if ytest is not None:
+            mu, Sig = self.obj.predict(self.delays, self.alpha, self.rho, ttest)
+            s2 = np.concatenate([np.asarray(a, dtype=np.float64) for a in sigmatest]) ** 2
+            Sig = Sig + np.diag(s2)                                       # + Sobs*, :317-319
+            yv = np.concatenate([np.asarray(a, dtype=np.float64) for a in ytest])
+            try:
+                return mvnormal_logpdf(mu, Sig, yv, device=self.obj.device)
+            except PosDefException as e:
+                # the reference retries with MiscUtil.nearestposdef(Sigma; minimumeigenvalue = 1e-6) (:327-341);
+                # MiscUtil's source is not available, so the fallback is not restated here
+                raise PosDefException(e.info) from None
+        if joint:
+            return self.obj.predict(self.delays, self.alpha, self.rho, [np.asarray(a, dtype=np.float64) for a in ttest])
+        tt = np.asarray(ttest, dtype=np.float64).ravel()
+        n = len(tt)
+        mu, Sig = self.obj.predict(self.delays, self.alpha, self.rho, [tt] * L)
+        d = np.diag(Sig)
+        return ([mu[l * n:(l + 1) * n] for l in range(L)],
+                [np.sqrt(np.maximum(d[l * n:(l + 1) * n], 1e-6)) for l in range(L)])      # :301-303
+
+
+def gpcc(tarray, yarray, stdarray, *, kernel, delays, iterations, seed=1, numberofrestarts=1, initialrandom=5,
+         rhomin=0.1, rhomax, device=0):
+    """loglikel, pred, (alpha, postb, rho) = gpcc(tarray, yarray, stdarray; kernel, delays, iterations, ...)
+    -- src/gpccfixdelay_marginaliseb.jl:46-53.  postb is returned as (mu_postb, Sigma_postb), the
+    parameters of the reference's MvNormal (:252)."""
+    delays = np.asarray(delays, dtype=np.float64)
+    assert len(delays) == len(tarray) == len(yarray) == len(stdarray)              # :78
+    obj = Objective(tarray, yarray, stdarray, kernel, marginalise_b=True, device=device)
+    res = gpcc_grid(tarray, yarray, stdarray, kernel=kernel, candidatedelays=delays[None, :], iterations=iterations,
+                    seed=seed, numberofrestarts=numberofrestarts, initialrandom=initialrandom, rhomin=rhomin,
+                    rhomax=rhomax, objective=obj)
+    alpha, rho = res.alpha[0], float(res.rho[0])
+    postb = obj.posterior_offsets(delays, alpha, rho)
+    return float(res.loglikel[0]), Predictor(obj, delays, alpha, rho), (alpha, postb, rho)

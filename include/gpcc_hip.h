@@ -104,6 +104,12 @@ int gpcc_predict(gpcc_handle_t handle, const double *delays, const double *alpha
 int gpcc_posterior_offsets(gpcc_handle_t handle, const double *delays, const double *alpha, double rho,
                            double *mu_postb, double *Sigma_postb, int *info);
 
+/* logpdf(MvNormal(mu, Sigma), x) for an explicit dense Sigma (column-major n x n; mu may be NULL = 0):
+ * the test log-likelihood of predictTest(ttest, ytest, sigmatest), src/gpccfixdelay_marginaliseb.jl:311-343
+ * (:325).  info > 0 is the PosDefException the reference catches at :327-341. */
+int gpcc_mvnormal_logpdf(int n, const double *Sigma, const double *mu, const double *x, double *loglik,
+                         int *info, int device_id);
+
 /* delayedCovariance(kernel, scale, delays, rho, x, y) of src/delayedCovariance.jl:1-35 (pass
  * y == x, Ny == Nx for the 5-argument form, :38).  out is column-major (sum Nx) x (sum Ny).
  * Returns GPCC_ERR_ARGUMENT with the reference's message for scale <= 0 / rho <= 0. */

@@ -291,3 +291,64 @@ def test_posterior_offsets_vs_reference_formulas(gp, oracle):
     mref = Sref @ (Q.T @ np.linalg.solve(K0, Y) + np.linalg.solve(Sigb, mub))       # :250
     np.testing.assert_allclose(Sig, Sref, rtol=1e-7, atol=1e-12)
     np.testing.assert_allclose(mu, mref, rtol=1e-7)
+
+
+def test_mvnormal_logpdf_dense(gp, oracle):
+    rng = np.random.default_rng(2)
+    for n in (1, 37, 128, 300):
+        A = rng.standard_normal((n, n))
+        Sig = A @ A.T + n * np.eye(n)
+        mu, x = rng.standard_normal(n), rng.standard_normal(n)
+        Lc = np.linalg.cholesky(Sig)
+        zz = np.linalg.solve(Lc, x - mu)
+        ref = -0.5 * (n * np.log(2 * np.pi) + 2 * np.sum(np.log(np.diag(Lc)))) - 0.5 * zz @ zz
+        assert abs(gp.mvnormal_logpdf(mu, Sig, x) - ref) <= 1e-10 * abs(ref)
+    with pytest.raises(gp.PosDefException):
+        gp.mvnormal_logpdf(np.zeros(3), np.diag([1.0, -1.0, 1.0]), np.zeros(3))
+
+
+def test_gpcc_end_to_end_small(gp, oracle):
+    """gpcc() on a simulatedata-sized problem (cfg1: 60 + 50 observations, iterations = 50, true delays):
+    the fit improves on the random start, pred() has the reference's three call forms, postb is sane."""
+    from gpcc_amd import synthetic
+    t, y, s, td = synthetic.simulate_lightcurves([60, 50], seed=1, gap_band=1, span=20.0)
+    loglikel, pred, (alpha, postb, rho) = gp.gpcc(t, y, s, kernel=gp.matern32, delays=td, iterations=50, rhomax=20.0)
+    ref, rinfo = oracle.loglik_batch("matern32", t, y, s, [td], [alpha], [rho], True)
+    assert rinfo[0] == 0 and abs(loglikel - ref[0]) <= 1e-8 * abs(ref[0])     # returned value == objective at the optimum
+    assert alpha.shape == (2,) and np.all(alpha > 0) and 0.1 < rho < 20.0
+    trange = np.arange(-10.0, 25.0, 0.5)
+    mu_b, sd_b = pred(trange)                                                  # per band (README.md:119-120)
+    assert len(mu_b) == 2 and mu_b[0].shape == trange.shape and np.all(sd_b[1] >= 1e-3)
+    mu_j, Sig_j = pred([trange, trange])                                       # joint
+    assert np.allclose(np.concatenate(mu_b), mu_j) and Sig_j.shape == (2 * len(trange),) * 2
+    mu_postb, Sig_postb = postb
+    assert abs(mu_postb[0] - np.mean(y[0])) < 3.0 and np.all(np.linalg.eigvalsh(Sig_postb) > 0)
+    # test log-likelihood (README.md:150-153): equals the dense formula with the joint prediction
+    tt = [np.array([9.0, 10.0, 11.0]), np.array([9.5, 10.5, 11.5])]
+    yt = [np.array([6.34, 5.49, 5.38]), np.array([13.08, 12.37, 15.69])]
+    st = [np.array([0.34, 0.42, 0.2]), np.array([0.87, 0.8, 0.66])]
+    got = pred(tt, yt, st)
+    mu, Sig = pred(tt)
+    Sig = Sig + np.diag(np.concatenate(st) ** 2)
+    r = np.concatenate(yt) - mu
+    refll = -0.5 * (6 * np.log(2 * np.pi) + np.linalg.slogdet(Sig)[1] + r @ np.linalg.solve(Sig, r))
+    assert abs(got - refll) <= 1e-9 * abs(refll)
+
+
+def test_gpcc_grid_device_matches_oracle_injected(gp, oracle):
+    """The lock-step fit over a small delay grid with the device objective vs the same host logic over the
+    oracle: optimised log-likelihoods agree (trajectories may differ in the last bits of the objective)."""
+    from gpcc_amd import fit, synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([60, 50], seed=1, gap_band=1, span=20.0)
+    grid = np.arange(0.0, 6.01, 1.0)
+    cand = np.stack([np.zeros_like(grid), grid], 1)
+    dev = gp.gpcc_grid(t, y, s, kernel=gp.OU, candidatedelays=cand, iterations=80, rhomax=20.0)
+
+    class O:
+        def loglik_batch(self, d, a, r):
+            return oracle.loglik_batch("OU", t, y, s, d, a, r, True, nthreads=8)
+
+    ref = fit.gpcc_grid(t, y, s, kernel="OU", candidatedelays=cand, iterations=80, rhomax=20.0, objective=O())
+    assert np.max(np.abs(dev.loglikel - ref.loglikel) / np.abs(ref.loglikel)) <= 1e-6
+    p = gp.getprobabilities(dev.loglikel)
+    assert abs(grid[np.argmax(p)] - 2.0) <= 1.0
