@@ -21,6 +21,7 @@ struct ProfRec { int which; hipEvent_t a, b; };
 struct gpcc_handle_s {
     int device = 0;
     int L = 0, N = 0, Np = 0, nt = 0, kernel_id = 0, mb = 1, precision = 0;
+    int nrhs = 1, woodbury = 0;   // fp32 + marginalised b: K0 in fp32, B through the capacitance matrix in fp64
     int Nl[GPCC_MAXL];
     double mean_b[GPCC_MAXL], sigma_b[GPCC_MAXL];
     std::vector<double> resid_host;
@@ -34,7 +35,7 @@ struct gpcc_handle_s {
     bool ws_ready = false;
     int ws_streams = 0, ws_slots = 0;
     double *d_tiles = nullptr, *d_linv = nullptr, *d_z = nullptr, *d_w = nullptr, *d_logdet = nullptr,
-           *d_quad = nullptr;
+           *d_quad = nullptr;   // d_quad: Gram matrices (slots x MAXRHS^2)
     int *d_info = nullptr;
     long slot_stride = 0;
     hipStream_t str[GPCC_MAX_STREAMS] = {};
@@ -98,9 +99,8 @@ extern "C" int gpcc_create(gpcc_handle_t *out, int L, const int *Nl, const doubl
     if (L < 1 || L > GPCC_MAXL) return fail(nullptr, GPCC_ERR_ARGUMENT, "L=%d outside [1,%d]", L, GPCC_MAXL);
     if (!Nl || !t || !y || !sigma) return fail(nullptr, GPCC_ERR_ARGUMENT, "NULL light-curve pointer");
     if (kernel_id < 0 || kernel_id > 3) return fail(nullptr, GPCC_ERR_ARGUMENT, "unknown kernel_id %d", kernel_id);
-    if (precision == GPCC_PRECISION_FP32)
-        return fail(nullptr, GPCC_ERR_UNSUPPORTED, "fp32 precision is not implemented in this build");
-    if (precision != GPCC_PRECISION_FP64) return fail(nullptr, GPCC_ERR_ARGUMENT, "unknown precision %d", precision);
+    if (precision != GPCC_PRECISION_FP64 && precision != GPCC_PRECISION_FP32)
+        return fail(nullptr, GPCC_ERR_ARGUMENT, "unknown precision %d", precision);
     long N = 0;
     for (int l = 0; l < L; ++l) {
         if (Nl[l] < 1 || (marginalise_b && Nl[l] < 2))
@@ -118,15 +118,17 @@ extern "C" int gpcc_create(gpcc_handle_t *out, int L, const int *Nl, const doubl
     h->N = (int)N;
     h->nt = (int)((N + GPCC_TILE - 1) / GPCC_TILE);
     h->Np = h->nt * GPCC_TILE;
+    h->kernel_id = kernel_id;
+    h->mb = marginalise_b ? 1 : 0;
+    h->precision = precision;
+    h->woodbury = (precision == GPCC_PRECISION_FP32 && marginalise_b) ? 1 : 0;
+    h->nrhs = h->woodbury ? L + 1 : 1;
     {   // default group size: 256 evaluations resident (one per CU in the diagonal step), capped at 64 GiB
-        const double per_slot = ((double)h->nt * (h->nt + 1) / 2 + 1) * GPCC_TILE_ELEMS * 8.0 + 16.0 * h->Np;
+        const double per_slot = ((double)h->nt * (h->nt + 1) / 2 + 1) * GPCC_TILE_ELEMS * (precision ? 4.0 : 8.0) + 16.0 * h->Np * (L + 1);
         long cap = (long)(64.0 * 1024 * 1024 * 1024 / per_slot);
         if (cap < 8) cap = 8;
         if (h->slots_per_stream > cap) h->slots_per_stream = (int)(cap / 8 * 8);
     }
-    h->kernel_id = kernel_id;
-    h->mb = marginalise_b ? 1 : 0;
-    h->precision = precision;
     std::vector<double> ht(h->Np, 0.0), hs(h->Np, 0.0), hr(h->Np, 0.0), hy(h->Np, 0.0);
     std::vector<int> hb(h->Np, -1);
     long off = 0;
@@ -234,7 +236,8 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "lds_dma")) return h->lds_dma;
     if (!strcmp(key, "N")) return h->N;
     if (!strcmp(key, "Np")) return h->Np;
-    if (!strcmp(key, "bytes_per_slot")) return (long)(((long)h->nt * (h->nt + 1) / 2 + 1) * GPCC_TILE_ELEMS + 2L * h->Np) * 8;
+    if (!strcmp(key, "bytes_per_slot")) return (long)(((long)h->nt * (h->nt + 1) / 2 + 1) * GPCC_TILE_ELEMS) * (h->precision ? 4 : 8) + 16L * h->Np * h->nrhs;
+    if (!strcmp(key, "precision")) return h->precision;
     return -1;
 }
 
@@ -250,10 +253,12 @@ extern "C" int gpcc_get_constants(gpcc_handle_t h, double *mean_b, double *Sigma
 // the diagonal kernel needs 149 KiB of dynamic LDS, the MFMA kernels 64 KiB (per device, idempotent)
 static int set_kernel_attributes(gpcc_handle_t h)
 {
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_diag_factor, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  GPCC_DIAG_LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_diag_factor<double>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_DIAG_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_diag_factor<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_DIAG_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<double>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_trsm<double>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_trsm<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
     return 0;
 }
 
@@ -265,12 +270,13 @@ static int ensure_workspace(gpcc_handle_t h)
     free_workspace(h);
     const long slots = (long)h->streams * h->slots_per_stream;
     h->slot_stride = ((long)h->nt * (h->nt + 1) / 2) * GPCC_TILE_ELEMS;
-    HIPCHK(h, hipMalloc(&h->d_tiles, sizeof(double) * h->slot_stride * slots));
-    HIPCHK(h, hipMalloc(&h->d_linv, sizeof(double) * GPCC_TILE_ELEMS * slots));
-    HIPCHK(h, hipMalloc(&h->d_z, sizeof(double) * h->Np * slots));
-    HIPCHK(h, hipMalloc(&h->d_w, sizeof(double) * h->Np * slots));
+    const size_t esz = h->precision ? sizeof(float) : sizeof(double);
+    HIPCHK(h, hipMalloc(&h->d_tiles, esz * h->slot_stride * slots));
+    HIPCHK(h, hipMalloc(&h->d_linv, esz * GPCC_TILE_ELEMS * slots));
+    HIPCHK(h, hipMalloc(&h->d_z, sizeof(double) * h->Np * h->nrhs * slots));
+    HIPCHK(h, hipMalloc(&h->d_w, sizeof(double) * h->Np * h->nrhs * slots));
     HIPCHK(h, hipMalloc(&h->d_logdet, sizeof(double) * slots));
-    HIPCHK(h, hipMalloc(&h->d_quad, sizeof(double) * slots));
+    HIPCHK(h, hipMalloc(&h->d_quad, sizeof(double) * GPCC_MAXRHS * GPCC_MAXRHS * slots));
     HIPCHK(h, hipMalloc(&h->d_info, sizeof(int) * slots));
     for (int s = 0; s < h->streams; ++s) {
         HIPCHK(h, hipStreamCreateWithFlags(&h->str[s], hipStreamNonBlocking));
@@ -287,12 +293,13 @@ static GpccCtx make_ctx(gpcc_handle_t h)
 {
     GpccCtx c;
     c.tiles = h->d_tiles; c.linv = h->d_linv; c.z = h->d_z; c.w = h->d_w;
-    c.logdet = h->d_logdet; c.quad = h->d_quad; c.info = h->d_info;
+    c.logdet = h->d_logdet; c.gram = h->d_quad; c.info = h->d_info;
     c.t = h->d_t; c.sig2 = h->d_sig2; c.resid = h->d_resid; c.band = h->d_band; c.yv = h->d_yv;
     for (int l = 0; l < GPCC_MAXL; ++l) c.sigma_b[l] = (l < h->L) ? h->sigma_b[l] : 0.0;
     c.slot_stride = h->slot_stride;
     c.L = h->L; c.N = h->N; c.Np = h->Np; c.nt = h->nt; c.kernel_id = h->kernel_id; c.marginalise_b = h->mb;
     c.nt_fact = h->nt;
+    c.nrhs = h->nrhs; c.woodbury = h->woodbury;
     return c;
 }
 
@@ -308,58 +315,66 @@ struct ProfScope {
     }
 };
 
-template <bool EXT>
+template <bool EXT, typename T>
 static void launch_assemble_t(const GpccCtx &c, const GpccGroup &g, hipStream_t s)
 {
     dim3 grid(c.nt * c.nt, g.cnt);
     switch (c.kernel_id) {
-    case 0: gpcc_assemble_tiles<0, EXT><<<grid, 256, 0, s>>>(c, g); break;
-    case 1: gpcc_assemble_tiles<1, EXT><<<grid, 256, 0, s>>>(c, g); break;
-    case 2: gpcc_assemble_tiles<2, EXT><<<grid, 256, 0, s>>>(c, g); break;
-    default: gpcc_assemble_tiles<3, EXT><<<grid, 256, 0, s>>>(c, g); break;
+    case 0: gpcc_assemble_tiles<0, EXT, T><<<grid, 256, 0, s>>>(c, g); break;
+    case 1: gpcc_assemble_tiles<1, EXT, T><<<grid, 256, 0, s>>>(c, g); break;
+    case 2: gpcc_assemble_tiles<2, EXT, T><<<grid, 256, 0, s>>>(c, g); break;
+    default: gpcc_assemble_tiles<3, EXT, T><<<grid, 256, 0, s>>>(c, g); break;
     }
 }
 
-static void launch_assemble(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s, bool ext)
+static void launch_assemble(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s, bool ext, bool f32)
 {
     ProfScope p(h, GPCC_PROF_ASSEMBLE, s);
-    if (ext) launch_assemble_t<true>(c, g, s);
-    else launch_assemble_t<false>(c, g, s);
+    if (f32) { if (ext) launch_assemble_t<true, float>(c, g, s); else launch_assemble_t<false, float>(c, g, s); }
+    else { if (ext) launch_assemble_t<true, double>(c, g, s); else launch_assemble_t<false, double>(c, g, s); }
 }
 
-// assemble + left-looking blocked Cholesky + fused forward solve for one group on stream s
-static int enqueue_factor(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s);
+static int enqueue_factor(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s, bool f32);
 
 static int enqueue_group(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s, bool factor = true,
-                         bool ext = false)
+                         bool ext = false, int f32 = -1)
 {
-    launch_assemble(h, c, g, s, ext);
+    const bool single = (f32 < 0) ? (h->precision == GPCC_PRECISION_FP32) : (f32 != 0);
+    launch_assemble(h, c, g, s, ext, single);
     if (!factor) return 0;
-    return enqueue_factor(h, c, g, s);
+    return enqueue_factor(h, c, g, s, single);
 }
 
 // left-looking blocked Cholesky + fused forward solve (+ Schur complement of non-factorised rows)
-static int enqueue_factor(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s)
+template <typename T>
+static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s)
 {
     const int cnt8 = 8 * ((g.cnt + 7) / 8);
     for (int k = 0; k < c.nt_fact; ++k) {
         if (k > 0) {
             ProfScope p(h, GPCC_PROF_PANEL_UPDATE, s);
-            gpcc_panel_update<<<cnt8 * (c.nt - k), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, k);
+            gpcc_panel_update<T><<<cnt8 * (c.nt - k), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, k);
         }
         {
             ProfScope p(h, GPCC_PROF_DIAG, s);
-            gpcc_diag_factor<<<g.cnt, 256, GPCC_DIAG_LDS_BYTES, s>>>(c, g, k);
+            gpcc_diag_factor<T><<<g.cnt, 256, GPCC_DIAG_LDS_BYTES, s>>>(c, g, k);
         }
         if (k < c.nt - 1) {
             ProfScope p(h, GPCC_PROF_TRSM, s);
-            gpcc_panel_trsm<<<cnt8 * (c.nt - k - 1), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
+            gpcc_panel_trsm<T><<<cnt8 * (c.nt - k - 1), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
         }
     }
     // augmented systems: Schur complement of the rows beyond the factorised columns,
     // S = C - V^T V with V = L^-1 [cross block]  
     for (int k = c.nt_fact; k < c.nt; ++k)
-        gpcc_panel_update<<<cnt8 * (c.nt - k), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, c.nt_fact);
+        gpcc_panel_update<T><<<cnt8 * (c.nt - k), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, c.nt_fact);
+}
+
+// left-looking blocked Cholesky + fused forward solve (+ Schur complement of non-factorised rows)
+static int enqueue_factor(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s, bool f32)
+{
+    if (f32) enqueue_factor_t<float>(h, c, g, s);
+    else enqueue_factor_t<double>(h, c, g, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, GPCC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return 0;
@@ -438,57 +453,6 @@ extern "C" int gpcc_loglik_batch(gpcc_handle_t h, int M, const double *delays, c
     return 0;
 }
 
-// one evaluation into slot 0, then a dense export (symmetric K, or the factor L)
-static int single_eval_export(gpcc_handle_t h, const double *delays, const double *alpha, double rho, double *out,
-                              int *info, bool factor)
-{
-    if (!h || !delays || !alpha || !out) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
-    int rc = set_device(h, h->device);
-    if (rc) return rc;
-    rc = ensure_workspace(h);
-    if (rc) return rc;
-    rc = ensure_staging(h, 1);
-    if (rc) return rc;
-    for (int l = 0; l < h->L; ++l)
-        if (!(alpha[l] > 0.0)) return fail(h, GPCC_ERR_ARGUMENT, "AssertionError: all(scale .> 0)");
-    if (rho <= 0.0) return fail(h, GPCC_ERR_ARGUMENT, "ρ=%.8f is <= 0", rho);
-    hipStream_t s = h->str[0];
-    double *dd = h->d_par, *da = h->d_par + h->L, *dr = h->d_par + 2 * h->L;
-    HIPCHK(h, hipMemcpyAsync(dd, delays, sizeof(double) * h->L, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(da, alpha, sizeof(double) * h->L, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(dr, &rho, sizeof(double), hipMemcpyHostToDevice, s));
-    const GpccCtx c = make_ctx(h);
-    GpccGroup g;
-    g.delays = dd; g.alpha = da; g.rho = dr; g.out_loglik = h->d_out; g.out_info = h->d_oinfo;
-    g.first = 0; g.slot0 = 0; g.cnt = 1;
-    const bool was_prof = h->prof;
-    h->prof = false;
-    rc = enqueue_group(h, c, g, s, factor);
-    h->prof = was_prof;
-    if (rc) return rc;
-    double *d_dense = nullptr;
-    const long nn = (long)h->N * h->N;
-    HIPCHK(h, hipMalloc(&d_dense, sizeof(double) * nn));
-    gpcc_export_dense<<<(unsigned)((nn + 255) / 256), 256, 0, s>>>(c, 0, d_dense, factor ? 0 : 1, 0, h->N, 0.0);
-    hipError_t e = hipMemcpyAsync(out, d_dense, sizeof(double) * nn, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess && factor && info) e = hipMemcpyAsync(info, h->d_oinfo, sizeof(int), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    hipFree(d_dense);
-    if (e != hipSuccess) return fail(h, GPCC_ERR_HIP, "dense export failed: %s", hipGetErrorString(e));
-    return 0;
-}
-
-extern "C" int gpcc_model_matrix(gpcc_handle_t h, const double *delays, const double *alpha, double rho, double *K_out)
-{
-    return single_eval_export(h, delays, alpha, rho, K_out, nullptr, false);
-}
-
-extern "C" int gpcc_factor_dense(gpcc_handle_t h, const double *delays, const double *alpha, double rho,
-                                 double *L_out, int *info)
-{
-    return single_eval_export(h, delays, alpha, rho, L_out, info, true);
-}
-
 // ------------------------------------------------------------------------------------------
 // Augmented systems (prediction, posterior of the offsets).  The points of the handle are followed,
 // from the next tile boundary on, by `next` extra rows (test points, or explicit rows Q / Y); only
@@ -509,11 +473,11 @@ struct AugRun {
 };
 
 static int run_augmented(gpcc_handle_t h, const double *delays, const double *alpha, double rho, int next,
-                         const double *ext_t, const int *ext_band, int marginalise_b, AugRun &a)
+                         const double *ext_t, const int *ext_band, int marginalise_b, AugRun &a, bool factor = true)
 {
     int rc = set_device(h, h->device);
     if (rc) return rc;
-    rc = ensure_workspace(h);   // streams + kernel attributes
+    rc = set_kernel_attributes(h);
     if (rc) return rc;
     rc = ensure_staging(h, 1);
     if (rc) return rc;
@@ -537,7 +501,7 @@ static int run_augmented(gpcc_handle_t h, const double *delays, const double *al
         band[off + i] = ext_band[i];
     }
     const long stride = ((long)nta * (nta + 1) / 2) * GPCC_TILE_ELEMS;
-    const size_t wsz = (size_t)stride + GPCC_TILE_ELEMS + 2 * (size_t)Npa + 2;
+    const size_t wsz = (size_t)stride + GPCC_TILE_ELEMS + 2 * (size_t)Npa + 1 + GPCC_MAXRHS * GPCC_MAXRHS;
     HIPCHK(h, hipMalloc(&a.d_pts, sizeof(double) * pts.size()));
     hipError_t e = hipMalloc(&a.d_band, sizeof(int) * Npa);
     if (e == hipSuccess) e = hipMalloc(&a.d_ws, sizeof(double) * wsz);
@@ -548,11 +512,12 @@ static int run_augmented(gpcc_handle_t h, const double *delays, const double *al
     GpccCtx c = make_ctx(h);
     c.t = a.d_pts; c.sig2 = a.d_pts + Npa; c.resid = a.d_pts + 2 * (size_t)Npa; c.yv = a.d_pts + 3 * (size_t)Npa;
     c.band = a.d_band;
-    c.tiles = a.d_ws; c.linv = a.d_ws + stride; c.z = c.linv + GPCC_TILE_ELEMS; c.w = c.z + Npa;
-    c.logdet = c.w + Npa; c.quad = c.logdet + 1; c.info = a.d_info;
+    c.tiles = a.d_ws; c.linv = a.d_ws + stride; c.z = a.d_ws + stride + GPCC_TILE_ELEMS; c.w = c.z + Npa;
+    c.logdet = c.w + Npa; c.gram = c.logdet + 1; c.info = a.d_info;
     c.slot_stride = stride; c.Np = Npa; c.nt = nta; c.nt_fact = h->nt; c.marginalise_b = marginalise_b;
+    c.nrhs = 1; c.woodbury = 0;   // the dense utilities always run the literal fp64 model
     if (!marginalise_b) for (int l = 0; l < GPCC_MAXL; ++l) c.sigma_b[l] = 0.0;
-    hipStream_t s = h->str[0];
+    hipStream_t s = h->main_stream;
     double *dd = h->d_par, *da = h->d_par + h->L, *dr = h->d_par + 2 * h->L;
     e = hipMemcpyAsync(dd, delays, sizeof(double) * h->L, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(da, alpha, sizeof(double) * h->L, hipMemcpyHostToDevice, s);
@@ -563,7 +528,7 @@ static int run_augmented(gpcc_handle_t h, const double *delays, const double *al
     g.first = 0; g.slot0 = 0; g.cnt = 1;
     const bool was_prof = h->prof;
     h->prof = false;
-    rc = enqueue_group(h, c, g, s, true, true);
+    rc = enqueue_group(h, c, g, s, factor, true, 0);
     h->prof = was_prof;
     if (rc) { a.release(); return rc; }
     a.c = c; a.off = off; a.next = next;
@@ -571,14 +536,15 @@ static int run_augmented(gpcc_handle_t h, const double *delays, const double *al
 }
 
 // copies the (extra x extra) block (symmetric, + jitter on the diagonal), z[extra], loglik and info back
-static int fetch_augmented(gpcc_handle_t h, AugRun &a, double *block, double *zext, double *loglik, int *info, double jitter)
+static int fetch_augmented(gpcc_handle_t h, AugRun &a, double *block, double *zext, double *loglik, int *info, double jitter,
+                           int symmetric = 1)
 {
-    hipStream_t s = h->str[0];
+    hipStream_t s = h->main_stream;
     const long nn = (long)a.next * a.next;
     double *d_dense = nullptr;
     hipError_t e = hipMalloc(&d_dense, sizeof(double) * nn);
     if (e == hipSuccess) {
-        gpcc_export_dense<<<(unsigned)((nn + 255) / 256), 256, 0, s>>>(a.c, 0, d_dense, 1, a.off, a.next, jitter);
+        gpcc_export_dense<double><<<(unsigned)((nn + 255) / 256), 256, 0, s>>>(a.c, 0, d_dense, symmetric, a.off, a.next, jitter);
         e = hipMemcpyAsync(block, d_dense, sizeof(double) * nn, hipMemcpyDeviceToHost, s);
     }
     if (e == hipSuccess && zext) e = hipMemcpyAsync(zext, a.c.z + a.off, sizeof(double) * a.next, hipMemcpyDeviceToHost, s);
@@ -593,6 +559,27 @@ static int fetch_augmented(gpcc_handle_t h, AugRun &a, double *block, double *ze
     if (loglik) *loglik = ll;
     if (info) *info = inf;
     return 0;
+}
+
+extern "C" int gpcc_model_matrix(gpcc_handle_t h, const double *delays, const double *alpha, double rho, double *K_out)
+{
+    if (!h || !delays || !alpha || !K_out) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
+    AugRun a;
+    int rc = run_augmented(h, delays, alpha, rho, 0, nullptr, nullptr, h->mb, a, false);
+    if (rc) return rc;
+    a.off = 0; a.next = h->N;
+    return fetch_augmented(h, a, K_out, nullptr, nullptr, nullptr, 0.0, 1);
+}
+
+extern "C" int gpcc_factor_dense(gpcc_handle_t h, const double *delays, const double *alpha, double rho,
+                                 double *L_out, int *info)
+{
+    if (!h || !delays || !alpha || !L_out) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
+    AugRun a;
+    int rc = run_augmented(h, delays, alpha, rho, 0, nullptr, nullptr, h->mb, a, true);
+    if (rc) return rc;
+    a.off = 0; a.next = h->N;
+    return fetch_augmented(h, a, L_out, nullptr, nullptr, info, 0.0, 0);
 }
 
 extern "C" int gpcc_predict(gpcc_handle_t h, const double *delays, const double *alpha, double rho, const int *Ntest,
@@ -672,7 +659,7 @@ extern "C" int gpcc_mvnormal_logpdf(int n, const double *Sigma, const double *mu
     if (rc) return fail(nullptr, rc, "%s", tmp.err.c_str());
     const int nt = (n + GPCC_TILE - 1) / GPCC_TILE, Np = nt * GPCC_TILE;
     const long stride = ((long)nt * (nt + 1) / 2) * GPCC_TILE_ELEMS;
-    const size_t wsz = (size_t)stride + GPCC_TILE_ELEMS + 2 * (size_t)Np + 4;
+    const size_t wsz = (size_t)stride + GPCC_TILE_ELEMS + 2 * (size_t)Np + 4 + GPCC_MAXRHS * GPCC_MAXRHS;
     std::vector<double> r(n);
     for (int i = 0; i < n; ++i) r[i] = x[i] - (mu ? mu[i] : 0.0);
     double *d_ws = nullptr, *d_in = nullptr;
@@ -685,14 +672,14 @@ extern "C" int gpcc_mvnormal_logpdf(int n, const double *Sigma, const double *mu
     if (e == hipSuccess) {
         GpccCtx c;
         memset(&c, 0, sizeof c);
-        c.tiles = d_ws; c.linv = d_ws + stride; c.z = c.linv + GPCC_TILE_ELEMS; c.w = c.z + Np;
-        c.logdet = c.w + Np; c.quad = c.logdet + 1; c.info = d_info;
+        c.tiles = d_ws; c.linv = d_ws + stride; c.z = d_ws + stride + GPCC_TILE_ELEMS; c.w = c.z + Np;
+        c.logdet = c.w + Np; c.gram = c.logdet + 1; c.info = d_info; c.nrhs = 1;
         c.slot_stride = stride; c.L = 1; c.N = n; c.Np = Np; c.nt = nt; c.nt_fact = nt;
         GpccGroup g;
         memset(&g, 0, sizeof g);
-        g.out_loglik = c.quad + 1; g.out_info = d_info + 1; g.cnt = 1;
-        gpcc_load_dense<<<nt * nt, 256>>>(c, 0, d_in, n, d_in + (size_t)n * n);
-        rc = enqueue_factor(&tmp, c, g, nullptr);
+        g.out_loglik = c.gram + GPCC_MAXRHS * GPCC_MAXRHS; g.out_info = d_info + 1; g.cnt = 1;
+        gpcc_load_dense<double><<<nt * nt, 256>>>(c, 0, d_in, n, d_in + (size_t)n * n);
+        rc = enqueue_factor(&tmp, c, g, nullptr, false);
         if (rc == 0) {
             e = hipMemcpy(loglik, g.out_loglik, sizeof(double), hipMemcpyDeviceToHost);
             if (e == hipSuccess) e = hipMemcpy(info, g.out_info, sizeof(int), hipMemcpyDeviceToHost);
@@ -851,6 +838,21 @@ extern "C" int gpcc_selftest(int device_id, double *tflops)
     for (int i = 0; i < 256; ++i)
         if (hD[i] != ref[i]) ++bad;
     if (bad) { hipFree(d); return fail(nullptr, GPCC_ERR_STATE, "f64 MFMA fragment map mismatch in %d of 256 elements", bad); }
+    {   // the same check for v_mfma_f32_16x16x4_f32 (different C/D register map)
+        float fA[64], fB[64], fD[256];
+        for (int i = 0; i < 64; ++i) { fA[i] = (float)hA[i]; fB[i] = (float)hB[i]; }
+        float *df = (float *)d;
+        e = hipMemcpy(df, fA, sizeof fA, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(df + 64, fB, sizeof fB, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            gpcc_selftest_map_f32<<<1, 64>>>(df, df + 64, df + 128);
+            e = hipMemcpy(fD, df + 128, sizeof fD, hipMemcpyDeviceToHost);
+        }
+        if (e != hipSuccess) { hipFree(d); return fail(nullptr, GPCC_ERR_HIP, "selftest: %s", hipGetErrorString(e)); }
+        for (int i = 0; i < 256; ++i)
+            if ((double)fD[i] != ref[i]) ++bad;
+        if (bad) { hipFree(d); return fail(nullptr, GPCC_ERR_STATE, "f32 MFMA fragment map mismatch in %d of 256 elements", bad); }
+    }
     if (tflops) {
         const int iters = 20000, blocks = 2048;
         hipEvent_t a, b;

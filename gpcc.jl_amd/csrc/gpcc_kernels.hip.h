@@ -2,38 +2,66 @@
 //
 // Data layout in HBM (DESIGN.md "Layout"): every evaluation owns one SLOT.  A slot stores the
 // lower triangle of its padded Np x Np matrix (Np = nt*128) as nt(nt+1)/2 TILES of 128x128
-// doubles; tile (I,J), J<=I, sits at ((I(I+1)/2)+J)*16384.  Inside a tile the 128 columns are
-// cut into 8 CHUNKS of 16; a chunk is 128 rows x 16 columns stored row-major = one contiguous
-// 16 KiB block that LDS-DMA copies 1:1 into LDS and from which the f64 MFMA fragments are read
-// with two ds_read_b128 per fragment.  Inside a row the eight 16-byte slots are XOR-swizzled
-// (gpcc_sw) so that those reads are bank-conflict-free; the swizzle lives in the HBM layout, so the
-// DMA stays a linear copy.  A row of tiles (I,0..I) is contiguous, so both operand streams of the
-// left-looking update are purely sequential reads.
+// elements (fp64 or fp32); tile (I,J), J<=I, sits at ((I(I+1)/2)+J)*16384 elements.  Inside a tile the
+// 128 columns are cut into CHUNKS of 16 KiB: 128 rows x 16 doubles (resp. 32 floats), row-major = one
+// contiguous block that LDS-DMA copies 1:1 into LDS and from which the MFMA fragments are read with two
+// ds_read_b128 per fragment.  Inside a row (128 bytes) the eight 16-byte slots are XOR-swizzled (gpcc_sw)
+// so that those reads are bank-conflict-free; the swizzle lives in the HBM layout, so the DMA stays a
+// linear copy.  A row of tiles (I,0..I) is contiguous, so both operand streams of the left-looking update
+// are purely sequential reads.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
 
 #define GPCC_TILE 128
-#define GPCC_KC 16
-#define GPCC_CHUNK (GPCC_TILE * GPCC_KC)        /* 2048 doubles = 16 KiB */
-#define GPCC_TILE_ELEMS (GPCC_TILE * GPCC_TILE) /* 16384 doubles = 128 KiB */
+#define GPCC_TILE_ELEMS (GPCC_TILE * GPCC_TILE) /* 16384 elements */
+#define GPCC_CHUNK_BYTES 16384
 #define GPCC_MAXL 8
+#define GPCC_MAXRHS (GPCC_MAXL + 1)
 #define GPCC_DIAG_LD 130
 #define GPCC_DINV_LD 17
-#define GPCC_DIAG_LDS_BYTES ((GPCC_TILE * GPCC_DIAG_LD + 8 * 16 * GPCC_DINV_LD + 2 * GPCC_TILE) * 8 + 16)
-#define GPCC_GEMM_LDS_BYTES (2 * 2 * GPCC_CHUNK * 8)
+#define GPCC_DIAG_LDS_BYTES \
+    ((GPCC_TILE * GPCC_DIAG_LD + 8 * 16 * GPCC_DINV_LD + GPCC_MAXRHS * GPCC_TILE + GPCC_TILE + GPCC_MAXRHS * GPCC_MAXRHS + 3) * 8 + 16)
+#define GPCC_GEMM_LDS_BYTES (2 * 2 * GPCC_CHUNK_BYTES)
 #define GPCC_GEMM_THREADS 512
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// Precision traits.  Both element types share the byte geometry (16 KiB chunks, 128-byte rows, two
+// 16-byte slots per fragment); they differ in the MFMA instruction and its C/D register map.
+template <typename T> struct GpccPrec;
+template <> struct GpccPrec<double> {
+    typedef d4 acc_t;   // 16x16 accumulator fragment: 4 values per lane
+    typedef d2 v16;     // one 16-byte LDS slot
+    static constexpr int KC = 16, EP = 2, KSTEPS = 4, NCH = 8;  // cols/chunk, elems/16 B, MFMA k-steps/chunk, chunks/tile
+    static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c)
+    {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    // v_mfma_f64_16x16x4_f64 C/D: col = lane&15, row = (lane>>4) + 4*reg   (gpcc_selftest checks it)
+    static __device__ __forceinline__ int crow(int q, int r) { return q + 4 * r; }
+};
+template <> struct GpccPrec<float> {
+    typedef f4 acc_t;
+    typedef f4 v16;
+    static constexpr int KC = 32, EP = 4, KSTEPS = 8, NCH = 4;
+    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    // v_mfma_f32_16x16x4_f32 C/D: col = lane&15, row = 4*(lane>>4) + reg
+    static __device__ __forceinline__ int crow(int q, int r) { return 4 * q + r; }
+};
 
 struct GpccCtx {
-    double *tiles;   // slots x slot_stride
-    double *linv;    // slots x 16384 : inverse of the current diagonal block, tile layout
-    double *z;       // slots x Np    : running right-hand side  r - L[:, :k] w[:k]
-    double *w;       // slots x Np    : w = L^-1 r
-    double *logdet;  // slots         : sum_i log L_ii
-    double *quad;    // slots         : |w|^2
+    void *tiles;     // slots x slot_stride elements (double or float)
+    void *linv;      // slots x 16384 : inverse of the current diagonal block, tile layout
+    double *z;       // slots x nrhs x Np : running right-hand sides  R - L[:, :k] W[:k]      (always fp64)
+    double *w;       // slots x nrhs x Np : W = L^-1 R
+    double *logdet;  // slots             : sum_i log L_ii
+    double *gram;    // slots x nrhs^2    : W^T W  (nrhs = 1: |w|^2 = sqmahal)
     int *info;       // slots
     const double *t, *sig2, *resid;  // Np (padding: 0)
     const double *yv;                // Np: raw fluxes (only read by explicit 'Y' rows, see band codes)
@@ -43,7 +71,10 @@ struct GpccCtx {
     double sigma_b[GPCC_MAXL];
     long slot_stride;
     int L, N, Np, nt, kernel_id, marginalise_b;
-    int nt_fact;  // tile columns that are factorised (== nt for the plain log-likelihood)
+    int nt_fact;   // tile columns that are factorised (== nt for the plain log-likelihood)
+    int nrhs;      // 1: R = Y - bbar.  L+1 (woodbury): R = [Q | Y - bbar]
+    int woodbury;  // 1: the matrix is K0 = delayedCovariance + Sobs only; B = Q Sigma_b Q' enters through the
+                   //    L x L capacitance matrix in fp64 (determinant lemma + Woodbury) -- the fp32 path
 };
 
 struct GpccGroup {
@@ -68,9 +99,12 @@ __device__ __forceinline__ int gpcc_sw(int r)
     const int p = (r >> 1) & 7;
     return (((p >> 2) & 1) << 2) | ((p & 1) << 1) | (((p >> 2) ^ (p >> 1)) & 1);
 }
+template <typename T>
 __device__ __forceinline__ int gpcc_elem_off(int r, int col)
 {
-    return (col >> 4) * GPCC_CHUNK + r * GPCC_KC + (((((col & 15) >> 1) ^ gpcc_sw(r)) << 1) | (col & 1));
+    typedef GpccPrec<T> P;
+    const int cc = col % P::KC;
+    return (col / P::KC) * (GPCC_TILE * P::KC) + r * P::KC + (((cc / P::EP) ^ gpcc_sw(r)) * P::EP) + (cc % P::EP);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -138,16 +172,19 @@ __device__ __forceinline__ double gpcc_kernel_eval(double xi, double xj, GpccKer
 }
 
 // ------------------------------------------------------------------------------------------
-// gpcc_assemble_tiles: K = delayedCovariance + Sobs + B for `cnt` evaluations, written once,
+// gpcc_assemble_tiles: K = delayedCovariance + Sobs (+ B) for `cnt` evaluations, written once,
 // lower-triangle tiles only, 16 B per lane fully coalesced (a workgroup store instruction
-// covers 4 KiB contiguous).  HBM-write-bound: 8 * 128*128 * nt(nt+1)/2 bytes per evaluation.
+// covers 4 KiB contiguous).  HBM-write-bound: sizeof(T) * 128*128 * nt(nt+1)/2 bytes per evaluation.
 // Replaces delayedCovariance.jl:23-31 + marginaliseb.jl:135 (+ Sobs + B) + :137 (symmetrise:
-// a no-op, K is exactly symmetric, so only the lower triangle is materialised).
+// a no-op, K is exactly symmetric, so only the lower triangle is materialised).  Elements are
+// evaluated in fp64 and rounded once when T = float.  In woodbury mode the B term is left out here
+// and the right-hand sides are [Q | Y - bbar].
 // grid (nt*nt, cnt), block 256.
 // ------------------------------------------------------------------------------------------
-template <int KID, bool EXT>
+template <int KID, bool EXT, typename T>
 __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup g)
 {
+    typedef GpccPrec<T> P;
     const int I = blockIdx.x / c.nt, J = blockIdx.x % c.nt;
     if (J > I) return;
     const int m = blockIdx.y, slot = g.slot0 + m, tid = threadIdx.x;
@@ -168,7 +205,7 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
         if (bad == 0 && rho <= 0.0) bad = -2;  // delayedCovariance.jl:5-7
         c.info[slot] = bad;
         c.logdet[slot] = 0.0;
-        c.quad[slot] = 0.0;
+        for (int i = 0; i < c.nrhs * c.nrhs; ++i) c.gram[(long)slot * GPCC_MAXRHS * GPCC_MAXRHS + i] = 0.0;
     }
     {
         const int side = tid >> 7, r = tid & 127;
@@ -179,40 +216,41 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
         sa[side][r] = (b >= 0) ? alpha[b] : 0.0;
         if (side == 0) {
             ssig[r] = c.sig2[gi];
-            if (I == J) c.z[(long)slot * c.Np + gi] = c.resid[gi];  // z <- Y - bbar
+            if (I == J) {  // right-hand sides: z <- Y - bbar (last column), woodbury: the columns of Q before it
+                double *zs = c.z + (long)slot * c.nrhs * c.Np;
+                for (int j = 0; j < c.nrhs - 1; ++j) zs[(long)j * c.Np + gi] = (b == j) ? 1.0 : 0.0;
+                zs[(long)(c.nrhs - 1) * c.Np + gi] = c.resid[gi];
+            }
         } else if (EXT) {
             syv[r] = c.yv[gi];
         }
     }
     __syncthreads();
 
-    double *T = c.tiles + (long)slot * c.slot_stride + gpcc_tile_off(I, J);
+    T *Tt = (T *)c.tiles + (long)slot * c.slot_stride + gpcc_tile_off(I, J);
     const bool diag = (I == J);
-    const bool mb = c.marginalise_b != 0;
+    const bool mb = c.marginalise_b != 0 && !c.woodbury;
     const int sp = tid & 7;  // this thread's 16-byte storage slot in every row it writes
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int r = (tid >> 3) + 32 * j;  // row data stays in registers across the 8 chunks
+        const int r = (tid >> 3) + 32 * j;  // row data stays in registers across the chunks
         const int br = sb[0][r];
         const double ur = su[0][r], ar = sa[0][r], sg = ssig[r];
         const double bterm = (mb && br >= 0) ? ssb[br] : 0.0;
-        const int cs = (sp ^ gpcc_sw(r)) << 1;  // logical column (inside a chunk) stored in slot sp
+        const int cs = (sp ^ gpcc_sw(r)) * P::EP;  // logical column (inside a chunk) stored in slot sp
 #pragma unroll
-        for (int ch = 0; ch < 8; ++ch) {
-            const int col = ch * 16 + cs;
-            const d2 uc = *(const d2 *)&su[1][col];
-            const d2 ac = *(const d2 *)&sa[1][col];
-            const int bc0 = sb[1][col], bc1 = sb[1][col + 1];
-            d2 v;
+        for (int ch = 0; ch < P::NCH; ++ch) {
+            const int col = ch * P::KC + cs;
+            typename P::v16 v;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < P::EP; ++h) {
                 const int cc = col + h;
-                const int bc = h ? bc1 : bc0;
-                const double kv = gpcc_kernel_eval<KID>(ur, uc[h], kc);  // x - delays[i] vs y - delays[j]
-                double val = (ar * ac[h]) * kv;                            // scale[i]*scale[j]*kernel
-                if (diag && r == cc) val = val + sg;                       // + Sobs
-                if (br == bc) val = val + bterm;                           // + B = Q Sigma_b Q'
-                if (br < 0 || bc < 0) val = (diag && r == cc) ? 1.0 : 0.0;  // identity padding
+                const int bc = sb[1][cc];
+                const double kv = gpcc_kernel_eval<KID>(ur, su[1][cc], kc);  // x - delays[i] vs y - delays[j]
+                double val = (ar * sa[1][cc]) * kv;                          // scale[i]*scale[j]*kernel
+                if (diag && r == cc) val = val + sg;                         // + Sobs
+                if (br == bc) val = val + bterm;                             // + B = Q Sigma_b Q'
+                if (br < 0 || bc < 0) val = (diag && r == cc) ? 1.0 : 0.0;   // identity padding
                 if (EXT) {  // explicit rows of an augmented system against real columns; 0 among themselves
                     if (br <= -2) {
                         const int e = -2 - br;
@@ -221,57 +259,55 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
                         val = 0.0;  // never read: explicit points come last, so they are rows of the lower triangle
                     }
                 }
-                v[h] = val;
+                v[h] = (T)val;
             }
-            *(d2 *)(T + ch * GPCC_CHUNK + r * GPCC_KC + sp * 2) = v;
+            *(typename P::v16 *)(Tt + ch * (GPCC_TILE * P::KC) + r * P::KC + sp * P::EP) = v;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// The fp64 MFMA kernels.  Measured on MI355X (tools/microbench.hip): v_mfma_f64_16x16x4_f64
+// The MFMA kernels.  Measured on MI355X (tools/microbench.hip): v_mfma_f64_16x16x4_f64
 // issues every 64 cycles per SIMD (77.6 TFLOP/s chip-wide) only when at least TWO waves of that
 // SIMD have MFMAs to issue -- one wave alone gets one per ~139 cycles whatever its number of
 // independent accumulators -- and VALU DFMA shares the same 78 TFLOP/s.  Hence: 8-wave workgroups,
-// a 32x64 (panel update) or 16x128 (panel solve) sub-tile per wave = 8 accumulators = 64 VGPRs,
+// a 32x64 (panel update) or 16x128 (panel solve) sub-tile per wave = 8 accumulators,
 // <= 128 VGPRs in all, two workgroups per CU = FOUR waves per SIMD, so barriers and LDS-DMA waits
-// of one wave are covered by three others.
+// of one wave are covered by three others.  The fp32 instantiation (v_mfma_f32_16x16x4_f32, 32 cycles)
+// has the same byte geometry: a 16 KiB chunk holds 32 k instead of 16 and costs 8 MFMA steps instead of 4.
 // Operands go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, the
 // 16 KiB chunk lands as a linear copy) into a 2-deep ring: 2 x (A 16 KiB + B 16 KiB) = 64 KiB.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void gpcc_dma_chunk(const double *gA, const double *gB, double *stage, int wave, int lane)
+template <typename T>
+__device__ __forceinline__ void gpcc_dma_chunk(const T *gA, const T *gB, T *stage, int wave, int lane)
 {
+    constexpr int PIECE = 1024 / sizeof(T), EP = 16 / sizeof(T), CH = GPCC_CHUNK_BYTES / sizeof(T);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int piece = wave * 2 + i;  // 16 pieces of 1 KiB per 16 KiB chunk, 8 waves x 2
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gA + piece * 128 + lane * 2),
-                                         (__attribute__((address_space(3))) void *)(stage + piece * 128), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gB + piece * 128 + lane * 2),
-                                         (__attribute__((address_space(3))) void *)(stage + GPCC_CHUNK + piece * 128), 16, 0,
-                                         0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gA + piece * PIECE + lane * EP),
+                                         (__attribute__((address_space(3))) void *)(stage + piece * PIECE), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gB + piece * PIECE + lane * EP),
+                                         (__attribute__((address_space(3))) void *)(stage + CH + piece * PIECE), 16, 0, 0);
     }
 }
 
-// One fragment = the 4 consecutive k (4q..4q+3) of one row: two swizzled 16-byte slots.
-__device__ __forceinline__ void gpcc_load_frag(const double *chunk, int row, int q, int sw, d2 &lo, d2 &hi)
-{
-    const double *p = chunk + row * GPCC_KC;
-    lo = *(const d2 *)(p + (((2 * q) ^ sw) << 1));
-    hi = *(const d2 *)(p + (((2 * q + 1) ^ sw) << 1));
-}
-
 // ------------------------------------------------------------------------------------------
-// gpcc_panel_update (step k, tile I >= k):  T(I,k) -= sum_{j<k} L(I,j) L(k,j)^T
+// gpcc_panel_update (step k, tile I >= k):  T(I,k) -= sum_{j<ktiles} L(I,j) L(k,j)^T
 // = LAPACK dpotrf's dsyrk/dgemm (reached from cholesky(K), marginaliseb.jl:139), left-looking:
-// the K-loop runs over the 8k chunks of the two contiguous tile rows I and k, the accumulator
+// the K-loop runs over the chunks of the two contiguous tile rows I and k, the accumulator
 // starts at -T(I,k) and is stored back negated (no read-modify-write).  The diagonal tile
 // (I == k, dsyrk) is computed in full like the others (4.5 % of the update flops are redundant).
 // Blocks of one evaluation share blockIdx % 8, i.e. (as dispatched) an XCD and its L2: they all
 // stream tile row k.
 // ------------------------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup g, int k, int ktiles)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+    typedef GpccPrec<T> P;
+    constexpr int CH = GPCC_CHUNK_BYTES / sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *smem = (T *)smem_raw;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, q = lane >> 4;
     const int sw = gpcc_sw(lr);
@@ -284,62 +320,60 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
     const int slot = g.slot0 + m;
     if (c.info[slot] != 0) return;
 
-    double *tiles = c.tiles + (long)slot * c.slot_stride;
-    const double *gA = tiles + gpcc_tile_off(I, 0);
-    const double *gB = tiles + gpcc_tile_off(k, 0);
-    double *T = tiles + gpcc_tile_off(I, k);
-    const int nch = 8 * ktiles;  // ktiles = k, or nt_fact for the Schur-complement tiles beyond the factorised columns
+    T *tiles = (T *)c.tiles + (long)slot * c.slot_stride;
+    const T *gA = tiles + gpcc_tile_off(I, 0);
+    const T *gB = tiles + gpcc_tile_off(k, 0);
+    T *Tt = tiles + gpcc_tile_off(I, k);
+    const int nch = P::NCH * ktiles;  // ktiles = k, or nt_fact for the Schur-complement tiles beyond the factorised columns
 
-    gpcc_dma_chunk(gA, gB, smem, wave, lane);
+    gpcc_dma_chunk<T>(gA, gB, smem, wave, lane);
 
-    // C/D map of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg (gpcc_selftest)
-    d4 acc[2][4];
+    typename P::acc_t acc[2][4];
 #pragma unroll
     for (int fm = 0; fm < 2; ++fm)
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                acc[fm][fn][r] = -T[gpcc_elem_off(wr * 32 + fm * 16 + q + 4 * r, wc * 64 + fn * 16 + lr)];
+                acc[fm][fn][r] = -Tt[gpcc_elem_off<T>(wr * 32 + fm * 16 + P::crow(q, r), wc * 64 + fn * 16 + lr)];
 
-    // per-lane LDS addresses: one base per 16-byte slot, fragments/stages are immediates from it
-    const double *pa0 = smem + (wr * 32 + lr) * GPCC_KC + (((2 * q) ^ sw) << 1);
-    const double *pa1 = smem + (wr * 32 + lr) * GPCC_KC + (((2 * q + 1) ^ sw) << 1);
-    const double *pb0 = smem + GPCC_CHUNK + (wc * 64 + lr) * GPCC_KC + (((2 * q) ^ sw) << 1);
-    const double *pb1 = smem + GPCC_CHUNK + (wc * 64 + lr) * GPCC_KC + (((2 * q + 1) ^ sw) << 1);
+    // per-lane LDS addresses: one base per 16-byte slot, fragments/stages are immediates from it.
+    // lane (lr, q) holds k = KSTEPS*q .. KSTEPS*q + KSTEPS-1 of its row: the MFMA sums over q, the steps over s
+    const T *pa0 = smem + (wr * 32 + lr) * P::KC + (((2 * q) ^ sw) * P::EP);
+    const T *pa1 = smem + (wr * 32 + lr) * P::KC + (((2 * q + 1) ^ sw) * P::EP);
+    const T *pb0 = smem + CH + (wc * 64 + lr) * P::KC + (((2 * q) ^ sw) * P::EP);
+    const T *pb1 = smem + CH + (wc * 64 + lr) * P::KC + (((2 * q + 1) ^ sw) * P::EP);
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int ch2 = 0; ch2 < nch; ch2 += 2) {
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {  // stage st holds chunk ch2+st (nch = 8k is even)
+        for (int st = 0; st < 2; ++st) {  // stage st holds chunk ch2+st (nch is even)
             const int ch = ch2 + st;
             if (ch + 1 < nch)
-                gpcc_dma_chunk(gA + (long)(ch + 1) * GPCC_CHUNK, gB + (long)(ch + 1) * GPCC_CHUNK,
-                               smem + (st ^ 1) * 2 * GPCC_CHUNK, wave, lane);
-            const int so = st * 2 * GPCC_CHUNK;
-            d2 a[2][2];
+                gpcc_dma_chunk<T>(gA + (long)(ch + 1) * CH, gB + (long)(ch + 1) * CH, smem + (st ^ 1) * 2 * CH, wave, lane);
+            const int so = st * 2 * CH;
+            typename P::v16 a[2][2];
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
-                a[f][0] = *(const d2 *)(pa0 + so + f * 16 * GPCC_KC);
-                a[f][1] = *(const d2 *)(pa1 + so + f * 16 * GPCC_KC);
+                a[f][0] = *(const typename P::v16 *)(pa0 + so + f * 16 * P::KC);
+                a[f][1] = *(const typename P::v16 *)(pa1 + so + f * 16 * P::KC);
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {  // column fragments two at a time (register budget: 128)
-                d2 b[2][2];
+                typename P::v16 b[2][2];
 #pragma unroll
                 for (int f = 0; f < 2; ++f) {
-                    b[f][0] = *(const d2 *)(pb0 + so + (2 * h + f) * 16 * GPCC_KC);
-                    b[f][1] = *(const d2 *)(pb1 + so + (2 * h + f) * 16 * GPCC_KC);
+                    b[f][0] = *(const typename P::v16 *)(pb0 + so + (2 * h + f) * 16 * P::KC);
+                    b[f][1] = *(const typename P::v16 *)(pb1 + so + (2 * h + f) * 16 * P::KC);
                 }
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < P::KSTEPS; ++s)
 #pragma unroll
                     for (int fm = 0; fm < 2; ++fm)
 #pragma unroll
                         for (int f = 0; f < 2; ++f)
-                            acc[fm][2 * h + f] = __builtin_amdgcn_mfma_f64_16x16x4f64(
-                                a[fm][s >> 1][s & 1], b[f][s >> 1][s & 1], acc[fm][2 * h + f], 0, 0, 0);
+                            acc[fm][2 * h + f] = P::mfma(a[fm][s / P::EP][s % P::EP], b[f][s / P::EP][s % P::EP], acc[fm][2 * h + f]);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -351,19 +385,23 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
         for (int fn = 0; fn < 4; ++fn)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                T[gpcc_elem_off(wr * 32 + fm * 16 + q + 4 * r, wc * 64 + fn * 16 + lr)] = -acc[fm][fn][r];
+                Tt[gpcc_elem_off<T>(wr * 32 + fm * 16 + P::crow(q, r), wc * 64 + fn * 16 + lr)] = -acc[fm][fn][r];
 }
 
 // ------------------------------------------------------------------------------------------
 // gpcc_panel_trsm (step k, tile I > k):  L(I,k) = T(I,k) inv(L_kk)^T  (dtrsm as an MFMA product
 // with the explicit 128x128 inverse from gpcc_diag_factor; chunks of inv(L_kk) above the diagonal
-// are zero and skipped), fused with the forward substitution of logpdf's whitening:
-// z_I -= L(I,k) w_k.  Each wave owns 16 rows x all 128 columns, so the k-range of every column
-// fragment is the same for all waves (balanced) and the row sums need no cross-wave reduction.
+// are zero and skipped), fused with the forward substitution of logpdf's whitening for every
+// right-hand side: Z_I -= L(I,k) W_k (fp64).  Each wave owns 16 rows x all 128 columns, so the k-range of
+// every column fragment is the same for all waves (balanced) and the row sums need no cross-wave reduction.
 // ------------------------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(512, 4) void gpcc_panel_trsm(GpccCtx c, GpccGroup g, int k)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+    typedef GpccPrec<T> P;
+    constexpr int CH = GPCC_CHUNK_BYTES / sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *smem = (T *)smem_raw;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, q = lane >> 4;
     const int sw = gpcc_sw(lr);
@@ -376,70 +414,84 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_trsm(GpccCtx c, GpccGroup g
     const int slot = g.slot0 + m;
     if (c.info[slot] != 0) return;
 
-    double *tiles = c.tiles + (long)slot * c.slot_stride;
-    double *T = tiles + gpcc_tile_off(I, k);
-    const double *gA = T;                                        // 8 chunks of T(I,k), overwritten at the end
-    const double *gB = c.linv + (long)slot * GPCC_TILE_ELEMS;    // inv(L_kk): rows = output column, k = j
+    T *tiles = (T *)c.tiles + (long)slot * c.slot_stride;
+    T *Tt = tiles + gpcc_tile_off(I, k);
+    const T *gA = Tt;                                               // the chunks of T(I,k), overwritten at the end
+    const T *gB = (const T *)c.linv + (long)slot * GPCC_TILE_ELEMS;  // inv(L_kk): rows = output column, k = j
 
-    gpcc_dma_chunk(gA, gB, smem, wave, lane);
-    d4 acc[8];
+    gpcc_dma_chunk<T>(gA, gB, smem, wave, lane);
+    typename P::acc_t acc[8];
 #pragma unroll
-    for (int fn = 0; fn < 8; ++fn) acc[fn] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int fn = 0; fn < 8; ++fn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[fn][r] = 0;
+    const T *pa0 = smem + (wave * 16 + lr) * P::KC + (((2 * q) ^ sw) * P::EP);
+    const T *pa1 = smem + (wave * 16 + lr) * P::KC + (((2 * q + 1) ^ sw) * P::EP);
+    const T *pb0 = smem + CH + lr * P::KC + (((2 * q) ^ sw) * P::EP);
+    const T *pb1 = smem + CH + lr * P::KC + (((2 * q + 1) ^ sw) * P::EP);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
-    for (int ch = 0; ch < 8; ++ch) {
-        double *cur = smem + (ch & 1) * 2 * GPCC_CHUNK;
-        if (ch + 1 < 8)
-            gpcc_dma_chunk(gA + (ch + 1) * GPCC_CHUNK, gB + (ch + 1) * GPCC_CHUNK, smem + ((ch + 1) & 1) * 2 * GPCC_CHUNK,
-                           wave, lane);
-        d2 a[2];
-        gpcc_load_frag(cur, wave * 16 + lr, q, sw, a[0], a[1]);
+    for (int ch = 0; ch < P::NCH; ++ch) {
+        const int so = (ch & 1) * 2 * CH;
+        if (ch + 1 < P::NCH)
+            gpcc_dma_chunk<T>(gA + (ch + 1) * CH, gB + (ch + 1) * CH, smem + ((ch + 1) & 1) * 2 * CH, wave, lane);
+        typename P::v16 a[2];
+        a[0] = *(const typename P::v16 *)(pa0 + so);
+        a[1] = *(const typename P::v16 *)(pa1 + so);
+        constexpr int FPC = P::KC / 16;  // column fragments per chunk width
 #pragma unroll
         for (int h = 0; h < 2; ++h) {  // column fragments in two groups of 4 (register budget)
-            if (4 * h + 3 < ch) continue;   // fragments left of chunk ch see only zeros of inv(L_kk)
-            d2 b[4][2];
+            if (4 * h + 3 < ch * FPC) continue;   // fragments left of chunk ch see only zeros of inv(L_kk)
+            typename P::v16 b[4][2];
 #pragma unroll
             for (int f = 0; f < 4; ++f)
-                if (4 * h + f >= ch) gpcc_load_frag(cur + GPCC_CHUNK, (4 * h + f) * 16 + lr, q, sw, b[f][0], b[f][1]);
+                if (4 * h + f >= ch * FPC) {
+                    b[f][0] = *(const typename P::v16 *)(pb0 + so + (4 * h + f) * 16 * P::KC);
+                    b[f][1] = *(const typename P::v16 *)(pb1 + so + (4 * h + f) * 16 * P::KC);
+                }
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < P::KSTEPS; ++s)
 #pragma unroll
                 for (int f = 0; f < 4; ++f)
-                    if (4 * h + f >= ch)
-                        acc[4 * h + f] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s >> 1][s & 1], b[f][s >> 1][s & 1],
-                                                                              acc[4 * h + f], 0, 0, 0);
+                    if (4 * h + f >= ch * FPC)
+                        acc[4 * h + f] = P::mfma(a[s / P::EP][s % P::EP], b[f][s / P::EP][s % P::EP], acc[4 * h + f]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    double *zp = c.z + (long)slot * c.Np + I * GPCC_TILE;
-    double wv[8];
 #pragma unroll
-    for (int fn = 0; fn < 8; ++fn) wv[fn] = c.w[(long)slot * c.Np + k * GPCC_TILE + fn * 16 + lr];
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int R = wave * 16 + q + 4 * r;
-        double p = 0.0;
+        for (int fn = 0; fn < 8; ++fn) Tt[gpcc_elem_off<T>(wave * 16 + P::crow(q, r), fn * 16 + lr)] = acc[fn][r];
+    for (int j = 0; j < c.nrhs; ++j) {
+        double *zp = c.z + ((long)slot * c.nrhs + j) * c.Np + I * GPCC_TILE;
+        const double *wp = c.w + ((long)slot * c.nrhs + j) * c.Np + k * GPCC_TILE;
+        double wv[8];
 #pragma unroll
-        for (int fn = 0; fn < 8; ++fn) {
-            const double xv = acc[fn][r];
-            T[gpcc_elem_off(R, fn * 16 + lr)] = xv;
-            p += xv * wv[fn];
+        for (int fn = 0; fn < 8; ++fn) wv[fn] = wp[fn * 16 + lr];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int R = wave * 16 + P::crow(q, r);
+            double p = 0.0;
+#pragma unroll
+            for (int fn = 0; fn < 8; ++fn) p += (double)acc[fn][r] * wv[fn];
+            p += __shfl_xor(p, 1);
+            p += __shfl_xor(p, 2);
+            p += __shfl_xor(p, 4);
+            p += __shfl_xor(p, 8);
+            if (lr == 0) zp[R] = zp[R] - p;
         }
-        p += __shfl_xor(p, 1);
-        p += __shfl_xor(p, 2);
-        p += __shfl_xor(p, 4);
-        p += __shfl_xor(p, 8);
-        if (lr == 0) zp[R] = zp[R] - p;
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // gpcc_diag_factor: step k's 128x128 diagonal block, one workgroup (4 waves) per evaluation, all in
-// LDS: blocked dpotf2 (16-wide panels), its triangular inverse (the B operand of the MFMA panel
-// solve), sum log L_ii (logdet of PDMat), w_k = inv(L_kk) z_k and |w_k|^2 (sqmahal); the last step
-// writes loglik = -(N log 2pi + 2 sum log L_ii)/2 - |w|^2/2  (Distributions.logpdf, marginaliseb.jl:139).
+// LDS and ALWAYS in fp64 (an fp32 tile is widened on load, inv(L_kk) and L_kk are rounded on store):
+// blocked dpotf2 (16-wide panels), its triangular inverse (the B operand of the MFMA panel
+// solve), sum log L_ii (logdet of PDMat), W_k = inv(L_kk) Z_k and the Gram matrix W^T W (sqmahal);
+// the last step writes loglik = -(N log 2pi + logdet K)/2 - (Y-bbar)' K^-1 (Y-bbar)/2
+// (Distributions.logpdf, marginaliseb.jl:139), in woodbury mode through the L x L capacitance matrix.
 //   per 16-block jb: (1) wave 0 factors the 16x16 diagonal block and inverts it in REGISTERS (lane =
 //   row resp. column, broadcasts by v_readlane);  (2) panel rows below: P = A inv(D)^T by MFMA;
 //   (3) trailing update C -= P P^T by MFMA.  Then inv(L) is assembled block-wise by MFMA: the
@@ -453,18 +505,22 @@ __device__ __forceinline__ double gpcc_bcast(double v, int srclane)
     return __hiloint2double(hi, lo);
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, int k)
 {
+    typedef GpccPrec<T> P;
+    typedef GpccPrec<double> PD;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int LD = GPCC_DIAG_LD, DLD = GPCC_DINV_LD;
-    double *sT = smem;                      // 128 x LD: lower = A -> L ; upper = inv(L)^T off-diagonal blocks
-    double *sDinv = sT + GPCC_TILE * LD;    // 8 x 16 x DLD: inverses of the 16x16 diagonal blocks
-    double *sz = sDinv + 8 * 16 * DLD;      // z_k, later w_k^2
-    double *sr = sz + GPCC_TILE;            // 128 log L_ii
-    int *sbad = (int *)(sr + GPCC_TILE);
+    double *sT = smem;                          // 128 x LD: lower = A -> L ; upper = inv(L)^T off-diagonal blocks
+    double *sDinv = sT + GPCC_TILE * LD;        // 8 x 16 x DLD: inverses of the 16x16 diagonal blocks
+    double *sz = sDinv + 8 * 16 * DLD;          // nrhs x 128: Z_k, later W_k
+    double *sr = sz + GPCC_MAXRHS * GPCC_TILE;  // 128 log L_ii
+    double *sG = sr + GPCC_TILE;                // nrhs x nrhs Gram matrix
+    int *sbad = (int *)(sG + GPCC_MAXRHS * GPCC_MAXRHS + 1);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, q = lane >> 4;
-    const int m = blockIdx.x, slot = g.slot0 + m;
+    const int m = blockIdx.x, slot = g.slot0 + m, nrhs = c.nrhs;
     const bool last = (k == c.nt_fact - 1);
     const int inf = c.info[slot];
     if (inf != 0) {
@@ -474,14 +530,15 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
         }
         return;
     }
-    double *tiles = c.tiles + (long)slot * c.slot_stride;
-    double *T = tiles + gpcc_tile_off(k, k);
-    for (int e = tid; e < GPCC_TILE_ELEMS; e += 256) {
-        const int ch = e >> 11, rem = e & 2047, r = rem >> 4, ks = rem & 15;  // ks: storage position
-        const int kk = ((((ks >> 1) ^ gpcc_sw(r)) << 1) | (ks & 1));
-        sT[r * LD + ch * 16 + kk] = T[e];
+    T *tiles = (T *)c.tiles + (long)slot * c.slot_stride;
+    T *Tt = tiles + gpcc_tile_off(k, k);
+    for (int e = tid; e < GPCC_TILE_ELEMS; e += 256) {  // e = storage position: consecutive threads, consecutive elements
+        const int ch = e / (GPCC_TILE * P::KC), rem = e % (GPCC_TILE * P::KC), r = rem / P::KC, ks = rem % P::KC;
+        const int kk = (((ks / P::EP) ^ gpcc_sw(r)) * P::EP) + (ks % P::EP);
+        sT[r * LD + ch * P::KC + kk] = (double)Tt[e];
     }
-    if (tid < GPCC_TILE) sz[tid] = c.z[(long)slot * c.Np + k * GPCC_TILE + tid];
+    for (int e = tid; e < nrhs * GPCC_TILE; e += 256)
+        sz[e] = c.z[((long)slot * nrhs + e / GPCC_TILE) * c.Np + k * GPCC_TILE + (e % GPCC_TILE)];
     if (tid == 0) *sbad = 0;
 
     for (int jb = 0; jb < 8; ++jb) {
@@ -536,7 +593,7 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
             }
             d4 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[s2], x, 0, 0, 0);
+            for (int s2 = 0; s2 < 4; ++s2) x = PD::mfma(av[s2], bv[s2], x);
 #pragma unroll
             for (int r = 0; r < 4; ++r) sT[(rf * 16 + q + 4 * r) * LD + r0 + lr] = x[r];
         }
@@ -551,8 +608,7 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
                 for (int r = 0; r < 4; ++r) x[r] = sT[(rf * 16 + q + 4 * r) * LD + cf * 16 + lr];
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2)
-                    x = __builtin_amdgcn_mfma_f64_16x16x4f64(-sT[(rf * 16 + lr) * LD + r0 + q + 4 * s2],
-                                                             sT[(cf * 16 + lr) * LD + r0 + q + 4 * s2], x, 0, 0, 0);
+                    x = PD::mfma(-sT[(rf * 16 + lr) * LD + r0 + q + 4 * s2], sT[(cf * 16 + lr) * LD + r0 + q + 4 * s2], x);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sT[(rf * 16 + q + 4 * r) * LD + cf * 16 + lr] = x[r];
             }
@@ -571,74 +627,124 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
                     const double av = sT[(i * 16 + lr) * LD + mm * 16 + q + 4 * s2];               // L[i][mm]
                     const double bv = (mm == j) ? sDinv[(j * 16 + q + 4 * s2) * DLD + lr]          // X[j][j][k][c]
                                                 : sT[(j * 16 + lr) * LD + mm * 16 + q + 4 * s2];   // X[mm][j]^T
-                    S = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, S, 0, 0, 0);
+                    S = PD::mfma(av, bv, S);
                 }
             }
             d4 Y = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int r = 0; r < 4; ++r)  // the accumulator S (row q+4r, col lr) IS the B operand of k-step r
-                Y = __builtin_amdgcn_mfma_f64_16x16x4f64(-sDinv[(i * 16 + lr) * DLD + q + 4 * r], S[r], Y, 0, 0, 0);
+                Y = PD::mfma(-sDinv[(i * 16 + lr) * DLD + q + 4 * r], S[r], Y);
 #pragma unroll
             for (int r = 0; r < 4; ++r) sT[(j * 16 + lr) * LD + i * 16 + q + 4 * r] = Y[r];   // X[i][j] transposed
         }
     }
     __syncthreads();
-    // ---- w_k = X z_k
-    double wi = 0.0;
+    // ---- W_k = X Z_k for every right-hand side
+    double wi[GPCC_MAXRHS];
+#pragma unroll
+    for (int j = 0; j < GPCC_MAXRHS; ++j) wi[j] = 0.0;
     if (tid < GPCC_TILE) {
         const int bi = tid >> 4;
-        for (int cc = 0; cc < bi * 16; ++cc) wi += sT[cc * LD + tid] * sz[cc];
-        for (int cc = bi * 16; cc <= tid; ++cc) wi += sDinv[(bi * 16 + (tid & 15)) * DLD + (cc & 15)] * sz[cc];
-        c.w[(long)slot * c.Np + k * GPCC_TILE + tid] = wi;
+        for (int cc = 0; cc <= tid; ++cc) {
+            const double xv = (cc < bi * 16) ? sT[cc * LD + tid] : sDinv[(bi * 16 + (tid & 15)) * DLD + (cc & 15)];
+#pragma unroll
+            for (int j = 0; j < GPCC_MAXRHS; ++j)
+                if (j < nrhs) wi[j] += xv * sz[j * GPCC_TILE + cc];
+        }
     }
     __syncthreads();
-    if (tid < GPCC_TILE) sz[tid] = wi * wi;
+    if (tid < GPCC_TILE) {
+#pragma unroll
+        for (int j = 0; j < GPCC_MAXRHS; ++j)
+            if (j < nrhs) {
+                sz[j * GPCC_TILE + tid] = wi[j];
+                c.w[((long)slot * nrhs + j) * c.Np + k * GPCC_TILE + tid] = wi[j];
+            }
+    }
     __syncthreads();
-    if (tid == 0) {  // fixed summation order: deterministic
-        double ld = 0.0, qd = 0.0;
-        for (int i = 0; i < GPCC_TILE; ++i) { ld += sr[i]; qd += sz[i]; }
+    if (tid < nrhs * nrhs) {  // Gram matrix, fixed summation order: deterministic
+        const int ga = tid / nrhs, gb = tid % nrhs;
+        double s = 0.0;
+        for (int i = 0; i < GPCC_TILE; ++i) s += sz[ga * GPCC_TILE + i] * sz[gb * GPCC_TILE + i];
+        double *gp = c.gram + (long)slot * GPCC_MAXRHS * GPCC_MAXRHS + tid;
+        s += *gp;
+        *gp = s;
+        sG[tid] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double ld = 0.0;
+        for (int i = 0; i < GPCC_TILE; ++i) ld += sr[i];
         ld += c.logdet[slot];
-        qd += c.quad[slot];
         c.logdet[slot] = ld;
-        c.quad[slot] = qd;
-        const int bad = *sbad;
+        int bad = *sbad;
         if (bad) c.info[slot] = k * GPCC_TILE + bad;
         if (last) {
             const double log2pi = 1.8378770664093454835606594728112;
-            g.out_loglik[g.first + m] = bad ? __builtin_nan("") : (-((double)c.N * log2pi + 2.0 * ld) / 2.0 - qd / 2.0);
-            g.out_info[g.first + m] = bad ? (k * GPCC_TILE + bad) : 0;
+            double logdetK = 2.0 * ld, quad = sG[nrhs * nrhs - 1];
+            if (c.woodbury && !bad) {
+                // K = K0 + Q Sigma_b Q':  logdet K = logdet K0 + sum log Sigma_b + logdet M,
+                // r'K^-1 r = r'K0^-1 r - v' M^-1 v,  M = Sigma_b^-1 + Q'K0^-1 Q, v = Q'K0^-1 r   (all from W'W)
+                // (in place in the LDS copy of the Gram matrix: M(a,b) = sG[a*nrhs+b], v(a) = sG[a*nrhs+L])
+                const int Lb = c.L;
+                for (int a = 0; a < Lb; ++a) {
+                    sG[a * nrhs + a] += 1.0 / c.sigma_b[a];
+                    logdetK += log(c.sigma_b[a]);
+                }
+                for (int j = 0; j < Lb; ++j) {  // Cholesky of M + forward solve
+                    double d = sG[j * nrhs + j];
+                    for (int p2 = 0; p2 < j; ++p2) d -= sG[j * nrhs + p2] * sG[j * nrhs + p2];
+                    if (!(d > 0.0)) { bad = c.N + 1 + j; break; }
+                    d = sqrt(d);
+                    sG[j * nrhs + j] = d;
+                    for (int i = j + 1; i < Lb; ++i) {
+                        double s = sG[i * nrhs + j];
+                        for (int p2 = 0; p2 < j; ++p2) s -= sG[i * nrhs + p2] * sG[j * nrhs + p2];
+                        sG[i * nrhs + j] = s / d;
+                    }
+                    double s = sG[j * nrhs + Lb];
+                    for (int p2 = 0; p2 < j; ++p2) s -= sG[j * nrhs + p2] * sG[p2 * nrhs + Lb];
+                    s /= d;
+                    sG[j * nrhs + Lb] = s;
+                    logdetK += 2.0 * log(d);
+                    quad -= s * s;
+                }
+            }
+            g.out_loglik[g.first + m] = bad ? __builtin_nan("") : (-((double)c.N * log2pi + logdetK) / 2.0 - quad / 2.0);
+            g.out_info[g.first + m] = bad ? ((bad > c.N) ? bad : k * GPCC_TILE + bad) : 0;
         }
     }
     // ---- write inv(L_kk) (B operand of the panel solve) and L_kk, both in tile layout
-    double *Linv = c.linv + (long)slot * GPCC_TILE_ELEMS;
+    T *Linv = (T *)c.linv + (long)slot * GPCC_TILE_ELEMS;
     for (int e = tid; e < GPCC_TILE_ELEMS; e += 256) {
-        const int ch = e >> 11, rem = e & 2047, r = rem >> 4, ks = rem & 15;
-        const int col = ch * 16 + ((((ks >> 1) ^ gpcc_sw(r)) << 1) | (ks & 1));
+        const int ch = e / (GPCC_TILE * P::KC), rem = e % (GPCC_TILE * P::KC), r = rem / P::KC, ks = rem % P::KC;
+        const int col = ch * P::KC + (((ks / P::EP) ^ gpcc_sw(r)) * P::EP) + (ks % P::EP);
         double xv = 0.0, lv = 0.0;
         if (col <= r) {
             xv = ((col >> 4) == (r >> 4)) ? sDinv[r * DLD + (col & 15)] : sT[col * LD + r];
             lv = sT[r * LD + col];
         }
-        Linv[e] = xv;
-        T[e] = lv;
+        Linv[e] = (T)xv;
+        Tt[e] = (T)lv;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// dense exports (tests, prediction): tiles of one slot -> column-major N x N
+// dense exports (tests, prediction): a square block of one slot's tiles -> column-major n x n
 // ------------------------------------------------------------------------------------------
+template <typename T>
 __global__ void gpcc_export_dense(GpccCtx c, int slot, double *out, int symmetric, int off, int n, double jitter)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)n * n) return;
     const int r0 = (int)(idx % n), c0 = (int)(idx / n);
     const int r = off + r0, col = off + c0;
-    const double *tiles = c.tiles + (long)slot * c.slot_stride;
+    const T *tiles = (const T *)c.tiles + (long)slot * c.slot_stride;
     double v;
     if (r >= col)
-        v = tiles[gpcc_tile_off(r >> 7, col >> 7) + gpcc_elem_off(r & 127, col & 127)];
+        v = (double)tiles[gpcc_tile_off(r >> 7, col >> 7) + gpcc_elem_off<T>(r & 127, col & 127)];
     else
-        v = symmetric ? tiles[gpcc_tile_off(col >> 7, r >> 7) + gpcc_elem_off(col & 127, r & 127)] : 0.0;
+        v = symmetric ? (double)tiles[gpcc_tile_off(col >> 7, r >> 7) + gpcc_elem_off<T>(col & 127, r & 127)] : 0.0;
     if (r0 == c0) v += jitter;
     out[idx] = v;
 }
@@ -649,17 +755,22 @@ __global__ void gpcc_export_dense(GpccCtx c, int slot, double *out, int symmetri
 // predictTest, marginaliseb.jl:311-343) then runs on the same factorisation kernels.
 // grid nt*nt, block 256.
 // ------------------------------------------------------------------------------------------
+template <typename T>
 __global__ void gpcc_load_dense(GpccCtx c, int slot, const double *dense, int n, const double *resid)
 {
     const int I = blockIdx.x / c.nt, J = blockIdx.x % c.nt;
     if (J > I) return;
     const int tid = threadIdx.x;
-    if (I == 0 && tid == 0) { c.info[slot] = 0; c.logdet[slot] = 0.0; c.quad[slot] = 0.0; }
-    double *T = c.tiles + (long)slot * c.slot_stride + gpcc_tile_off(I, J);
+    if (I == 0 && tid == 0) {
+        c.info[slot] = 0;
+        c.logdet[slot] = 0.0;
+        c.gram[(long)slot * GPCC_MAXRHS * GPCC_MAXRHS] = 0.0;
+    }
+    T *Tt = (T *)c.tiles + (long)slot * c.slot_stride + gpcc_tile_off(I, J);
     for (int e = tid; e < GPCC_TILE_ELEMS; e += 256) {
         const int r = e & 127, col = e >> 7;   // consecutive threads walk down a column of the dense input
         const long gr = (long)I * GPCC_TILE + r, gc = (long)J * GPCC_TILE + col;
-        T[gpcc_elem_off(r, col)] = (gr < n && gc < n) ? dense[gc * n + gr] : ((gr == gc) ? 1.0 : 0.0);
+        Tt[gpcc_elem_off<T>(r, col)] = (T)((gr < n && gc < n) ? dense[gc * n + gr] : ((gr == gc) ? 1.0 : 0.0));
     }
     if (I == J && tid < GPCC_TILE) {
         const long gr = (long)I * GPCC_TILE + tid;
@@ -738,4 +849,13 @@ __global__ __launch_bounds__(256) void gpcc_selftest_rate(double *sink, int iter
     }
     d4 s = a0 + a1 + a2 + a3;
     if (s[0] + s[1] + s[2] + s[3] == 12345.678) sink[0] = s[0];
+}
+
+__global__ void gpcc_selftest_map_f32(const float *A /*16x4 row-major*/, const float *B /*4x16 row-major*/,
+                                      float *D /*16x16 row-major*/)
+{
+    const int lane = threadIdx.x & 63, lr = lane & 15, q = lane >> 4;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = GpccPrec<float>::mfma(A[lr * 4 + q], B[q * 16 + lr], acc);
+    for (int r = 0; r < 4; ++r) D[GpccPrec<float>::crow(q, r) * 16 + lr] = acc[r];
 }

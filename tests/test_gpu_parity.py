@@ -352,3 +352,49 @@ def test_gpcc_grid_device_matches_oracle_injected(gp, oracle):
     assert np.max(np.abs(dev.loglikel - ref.loglikel) / np.abs(ref.loglikel)) <= 1e-6
     p = gp.getprobabilities(dev.loglikel)
     assert abs(grid[np.argmax(p)] - 2.0) <= 1.0
+
+
+# ---- fp32 path: K0 = delayedCovariance + Sobs factorised in fp32 (fp64 diagonal blocks and right-hand sides),
+# ---- the offset prior B = Q Sigma_b Q' through the L x L capacitance matrix in fp64.  Bar: 1e-3 relative.
+FP32_RTOL = 1e-3
+
+
+def test_fp32_golden_cases(gp, golden):
+    worst = 0.0
+    for c in golden["cases"]:
+        with gp.Objective(c["t"], c["y"], c["sigma"], c["kernel"], marginalise_b=c["marginalise_b"], precision="fp32",
+                          slots_per_stream=4) as obj:
+            ll, info = obj.loglik_batch([c["delays"]], [c["alpha"]], [c["rho"]])
+        assert info[0] == 0, (c["kernel"], c["marginalise_b"], info)
+        worst = max(worst, abs(ll[0] - c["loglik"]) / abs(c["loglik"]))
+    print("fp32 worst relative error vs golden: %.3e" % worst)
+    assert worst <= FP32_RTOL
+
+
+@pytest.mark.parametrize("kname,mb", [("matern52", True), ("matern32", True), ("OU", False), ("rbf", True)])
+def test_fp32_medium_vs_oracle(gp, oracle, kname, mb):
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([1024, 1024], seed=2, gap_band=1)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    rng = np.random.default_rng(3)
+    M = 12
+    delays = np.stack([np.zeros(M), rng.random(M) * 20], 1)
+    alphas = np.tile(alpha, (M, 1)) * (0.7 + 0.6 * rng.random((M, 2)))
+    rhos = 2.0 + 3 * rng.random(M)
+    ref, rinfo = oracle.loglik_batch(kname, t, y, s, delays, alphas, rhos, mb, nthreads=12)
+    with gp.Objective(t, y, s, kname, marginalise_b=mb, precision="fp32") as obj:
+        ll, info = obj.loglik_batch(delays, alphas, rhos)
+    ok = rinfo == 0
+    assert ok.sum() >= M // 2
+    assert (info[ok] == 0).all()
+    err = _rel(ll[ok], ref[ok])
+    print("fp32 %s mb=%s: max rel err %.3e" % (kname, mb, err))
+    assert err <= FP32_RTOL
+
+
+def test_fp32_status_codes(gp, golden):
+    c = golden["nonpd"]
+    with gp.Objective(c["t"], c["y"], c["sigma"], c["kernel"], marginalise_b=False, precision="fp32") as obj:
+        ll, info = obj.loglik_batch([c["delays"], c["delays"], c["delays"]], [c["alpha"], [1.0, -1.0], c["alpha"]],
+                                    [c["rho"], 1.0, 0.0])
+        assert info[0] > 0 and np.isnan(ll[0]) and info[1] == -1 and info[2] == -2
