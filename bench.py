@@ -27,6 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (vendor sheet; BASELINE.md "Bounds")
+FP32_MFMA_PEAK_TFLOPS = 157.3  # fp32-input MFMA (MI355X_MICROARCH.md: 157.3 spec, 155 measured)
 TILE = 128
 
 
@@ -67,6 +68,7 @@ def main():
     ap.add_argument("--grid", type=int, default=1024, help="delays per GPU per step")
     ap.add_argument("--n-per-band", type=int, default=2048)
     ap.add_argument("--kernel", default="matern32")
+    ap.add_argument("--precision", default="fp64", choices=["fp64", "fp32"])
     ap.add_argument("--streams", type=int, default=None)
     ap.add_argument("--slots", type=int, default=None)
     ap.add_argument("--lds-dma", type=int, default=None)
@@ -101,7 +103,7 @@ def main():
     lo = rank * G
     delays = np.stack([np.zeros(G), grid_all[lo:lo + G]], 1)
 
-    obj = gpcc_amd.Objective(t, y, s, args.kernel, marginalise_b=True, precision="fp64", device=local,
+    obj = gpcc_amd.Objective(t, y, s, args.kernel, marginalise_b=True, precision=args.precision, device=local,
                              streams=args.streams, slots_per_stream=args.slots, lds_dma=args.lds_dma)
     d_delays = torch.as_tensor(delays, device=dev).contiguous()
     d_alpha = torch.as_tensor(np.tile(alpha, (G, 1)), device=dev).contiguous()
@@ -163,15 +165,18 @@ def main():
             flops_per_launch = flops_eval * G / launches      # algorithmic flops / launch (average over steps k)
             achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
             traffic, tsrc = pmc_traffic("gpcc_panel_update", obj.get_option("slots_per_stream"), N)
+            peak = FP64_MFMA_PEAK_TFLOPS if args.precision == "fp64" else FP32_MFMA_PEAK_TFLOPS
+            if args.precision != "fp64":
+                traffic, tsrc = None, None
             roofline = {"bound": "mfma", "kernel": "gpcc_panel_update", "achieved": round(achieved, 3),
-                        "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
+                        "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                         "traffic": traffic, "traffic_source": tsrc, "launches": launches, "avg_launch_ms": round(avg_ms, 4),
                         "algorithmic_flops_per_launch": flops_per_launch,
                         "other_kernels_ms": {k: round(v[1], 3) for k, v in prof.items()}}
             # the HBM-bound assembly kernel, reported beside it
             an, ams = prof["assemble"]
             nt = (N + TILE - 1) // TILE
-            abytes = 8.0 * TILE * TILE * nt * (nt + 1) / 2 * G / max(an, 1)
+            abytes = (8.0 if args.precision == "fp64" else 4.0) * TILE * TILE * nt * (nt + 1) / 2 * G / max(an, 1)
             roofline["assemble"] = {"bound": "hbm", "achieved": round(abytes / (ams / max(an, 1) * 1e-3) / 1e9, 1),
                                     "peak": 8000.0, "unit": "GB/s", "avg_launch_ms": round(ams / max(an, 1), 4),
                                     "algorithmic_bytes_per_launch": abytes}
@@ -199,9 +204,9 @@ def main():
             "metric": "delay-grid loglik evals/sec (N=4096, 2-band Matern-3/2)",
             "value": round(value, 2), "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "2-band synthetic N=%d per band (N=%d), %s fp64, %d-point delay grid per GPU"
-                                   % (Nb, N, args.kernel, G),
+            "vs_baseline": None, "dtype": "f64" if args.precision == "fp64" else "f32", "data": "synthetic",
+            "config": {"workload": "2-band synthetic N=%d per band (N=%d), %s %s, %d-point delay grid per GPU"
+                                   % (Nb, N, args.kernel, args.precision, G),
                        "grid_total": Gtot, "streams": obj.get_option("streams"),
                        "slots_per_stream": obj.get_option("slots_per_stream"), "lds_dma": obj.get_option("lds_dma"),
                        "parallelism": "grid-sharded x%d, 1 all_gather" % world},

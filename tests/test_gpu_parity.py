@@ -398,3 +398,22 @@ def test_fp32_status_codes(gp, golden):
         ll, info = obj.loglik_batch([c["delays"], c["delays"], c["delays"]], [c["alpha"], [1.0, -1.0], c["alpha"]],
                                     [c["rho"], 1.0, 0.0])
         assert info[0] > 0 and np.isnan(ll[0]) and info[1] == -1 and info[2] == -2
+
+
+def test_cfg5_fp32_n16384_vs_fp64(gp):
+    """cfg5: 2 x 8192 (N = 16384), Matern-5/2, fp32.  The CPU oracle needs minutes per evaluation at this
+    size, so the fp32 path is checked against the fp64 device path (itself pinned to the oracle at
+    N <= 4096 above) on three delays; bar 1e-3 relative (BASELINE north_star)."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([8192, 8192], seed=1)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    delays = np.array([[0.0, 0.0], [0.0, 2.0], [0.0, 13.7]])
+    alphas, rhos = np.tile(alpha, (3, 1)), np.full(3, rho)
+    with gp.Objective(t, y, s, gp.matern52, precision="fp64", slots_per_stream=3) as o64:
+        ref, i64 = o64.loglik_batch(delays, alphas, rhos)
+    with gp.Objective(t, y, s, gp.matern52, precision="fp32", slots_per_stream=3) as o32:
+        ll, i32 = o32.loglik_batch(delays, alphas, rhos)
+    assert (i64 == 0).all() and (i32 == 0).all()
+    err = _rel(ll, ref)
+    print("cfg5 fp32 vs fp64 at N=16384: max rel err %.3e" % err)
+    assert err <= FP32_RTOL
