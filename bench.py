@@ -88,10 +88,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    ndev = torch.cuda.device_count()
+    if local >= ndev and os.environ.get("GPCC_BENCH_OVERSUBSCRIBE") == "1":
+        local = local % ndev          # rehearsal only: several ranks on one GPU (gloo collective below)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = os.environ.get("GPCC_BENCH_BACKEND", "nccl")   # "nccl" = RCCL; "gloo" only for one-GPU rehearsals
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     Nb = args.n_per_band
     t, y, s, _ = synthetic.simulate_lightcurves([Nb, Nb], seed=1)
@@ -118,7 +125,12 @@ def main():
     def step():
         obj.loglik_batch_device(d_delays, d_alpha, d_rho, out=d_ll, info=d_info)
         if world > 1:
-            dist.all_gather_into_tensor(d_all, d_ll)     # the path's single collective
+            if backend == "nccl":
+                dist.all_gather_into_tensor(d_all, d_ll)     # the path's single collective (RCCL over xGMI)
+            else:
+                host = torch.empty(Gtot, dtype=torch.float64)
+                dist.all_gather_into_tensor(host, d_ll.cpu())
+                d_all.copy_(host)
             src = d_all
         else:
             src = d_ll
@@ -140,7 +152,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

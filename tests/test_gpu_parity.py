@@ -417,3 +417,33 @@ def test_cfg5_fp32_n16384_vs_fp64(gp):
     err = _rel(ll, ref)
     print("cfg5 fp32 vs fp64 at N=16384: max rel err %.3e" % err)
     assert err <= FP32_RTOL
+
+
+def test_device_pointer_api_matches_host_api(gp):
+    """gpcc_loglik_batch_device (torch CUDA tensors, asynchronous on torch's stream) vs the host-pointer
+    form, and gpcc_probabilities_device vs getprobabilities."""
+    import ctypes
+
+    import torch
+
+    from gpcc_amd import _capi, synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([300, 280], seed=8)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    M = 37
+    grid = np.linspace(0.0, 10.0, M)
+    delays = np.stack([np.zeros(M), grid], 1)
+    dev = torch.device("cuda", 0)
+    with gp.Objective(t, y, s, gp.matern32, slots_per_stream=8, streams=2) as obj:
+        ref, rinfo = obj.loglik_batch(delays, np.tile(alpha, (M, 1)), np.full(M, rho))
+        side = torch.cuda.Stream(dev)
+        with torch.cuda.stream(side):   # a non-default caller stream: fork/join must order the work behind it
+            d_d = torch.as_tensor(delays, device=dev)
+            d_a = torch.as_tensor(np.tile(alpha, (M, 1)), device=dev)
+            d_r = torch.full((M,), float(rho), dtype=torch.float64, device=dev)
+            out, info = obj.loglik_batch_device(d_d, d_a, d_r)
+            prob = torch.empty(M, dtype=torch.float64, device=dev)
+            _capi.check(_capi.load().gpcc_probabilities_device(M, out.data_ptr(), None, prob.data_ptr(),
+                                                               ctypes.c_void_p(side.cuda_stream)))
+        side.synchronize()
+        assert np.array_equal(out.cpu().numpy(), ref) and np.array_equal(info.cpu().numpy(), rinfo)
+        np.testing.assert_allclose(prob.cpu().numpy(), gp.getprobabilities(ref), rtol=1e-12)
