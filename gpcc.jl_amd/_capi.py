@@ -4,6 +4,7 @@ This is the same boundary the Julia shim of INTEGRATION.md binds with `ccall`.  
 fallback: if the shared library is missing, or no HIP device is present, calls raise."""
 import ctypes
 import os
+import sys
 
 from .build import LIB_PATH
 
@@ -67,6 +68,12 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950).  gpcc_amd has no CPU fallback." % LIB_PATH)
+        if "torch" in sys.modules:
+            # torch wheels bundle their own HIP runtime; when both live in one process torch must
+            # initialise the GPU first (the other order has been seen to end in "No HIP GPUs are available")
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the library does not export the symbol

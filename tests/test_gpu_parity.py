@@ -14,6 +14,10 @@ LL_RTOL = 1e-8
 
 @pytest.fixture(scope="module")
 def gp():
+    # torch ships its own HIP runtime: when both live in one process, torch has to initialise the GPU
+    # first (initialising it after libgpcc_hip.so has run many kernels reported "No HIP GPUs").
+    import torch
+    torch.cuda.init()
     import gpcc_amd
     return gpcc_amd
 
@@ -56,12 +60,13 @@ def test_probabilities_golden(gp, golden):
     assert q.shape == ll.shape and abs(q.sum() - 1) < 1e-12
 
 
-@pytest.mark.parametrize("lds_dma", [0, 1])
-def test_loglik_golden_cases(gp, golden, lds_dma):
+@pytest.mark.parametrize("right_looking_max", [0, 16])   # left-looking (large groups) / right-looking (small groups)
+def test_loglik_golden_cases(gp, golden, right_looking_max):
     worst = 0.0
     for c in golden["cases"]:
         with gp.Objective(c["t"], c["y"], c["sigma"], c["kernel"], marginalise_b=c["marginalise_b"],
-                          lds_dma=lds_dma, slots_per_stream=4) as obj:
+                          slots_per_stream=4) as obj:
+            obj.set_option("right_looking_max", right_looking_max)
             ll, info = obj.loglik_batch([c["delays"]], [c["alpha"]], [c["rho"]])
         assert info[0] == 0
         worst = max(worst, abs(ll[0] - c["loglik"]) / abs(c["loglik"]))
@@ -101,8 +106,9 @@ def test_loglik_medium_vs_oracle_grouped(gp, oracle, kname):
     alpha = 0.5 + rng.random((M, 2)) * 2
     rho = 1.0 + rng.random(M) * 5
     ref, rinfo = oracle.loglik_batch(kname, t, y, s, delays, alpha, rho, True, nthreads=8)
-    for dma in (0, 1):
-        with gp.Objective(t, y, s, kname, slots_per_stream=4, streams=2, lds_dma=dma) as obj:
+    for rl in (0, 16):
+        with gp.Objective(t, y, s, kname, slots_per_stream=4, streams=2) as obj:
+            obj.set_option("right_looking_max", rl)
             ll, info = obj.loglik_batch(delays, alpha, rho)
             ok = rinfo == 0
             assert np.array_equal(info == 0, ok)
@@ -154,8 +160,11 @@ def test_full_size_properties_and_oracle(gp, oracle):
     delays = np.stack([np.zeros_like(grid), grid], 1)
     M = len(grid)
     with gp.Objective(t, y, s, gp.matern32) as obj:
-        ll, info = obj.loglik_batch(delays, np.tile(alpha, (M, 1)), np.full(M, rho))
+        ll, info = obj.loglik_batch(delays, np.tile(alpha, (M, 1)), np.full(M, rho))      # 12 <= 16: right-looking
         assert (info == 0).all()
+        obj.set_option("right_looking_max", 0)
+        ll_left, _ = obj.loglik_batch(delays, np.tile(alpha, (M, 1)), np.full(M, rho))    # left-looking
+        assert _rel(ll_left, ll) <= 1e-11
         # adding a constant to every delay leaves K unchanged
         ll_s, _ = obj.loglik_batch(delays + 3.5, np.tile(alpha, (M, 1)), np.full(M, rho))
         assert _rel(ll_s, ll) <= 1e-9
