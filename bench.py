@@ -46,7 +46,7 @@ def update_flops_per_eval(N):
     return total, per_step
 
 
-def pmc_traffic(kernel, slots, N):
+def pmc_traffic(kernel, slots, N, prec="fp64"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (bench.py cannot
     collect PMC counters itself); None if no summary matches this configuration."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -55,7 +55,10 @@ def pmc_traffic(kernel, slots, N):
             d = json.load(f)
         if d.get("slots") != slots or d.get("N") != N:
             return None, None
-        return d["kernels"][kernel]["hbm_bytes_per_launch"], "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+        for name, e in d["kernels"].items():   # template instantiations carry their arguments in the name
+            if name.startswith(kernel) and "hbm_bytes_per_launch" in e and ("<float" in name) == (prec == "fp32"):
+                return e["hbm_bytes_per_launch"], "profiles/pmc_latest.json: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % name
+        return None, None
     except Exception:
         return None, None
 
@@ -176,10 +179,8 @@ def main():
             avg_ms = total_ms / launches
             flops_per_launch = flops_eval * G / launches      # algorithmic flops / launch (average over steps k)
             achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            traffic, tsrc = pmc_traffic("gpcc_panel_update", obj.get_option("slots_per_stream"), N)
+            traffic, tsrc = pmc_traffic("gpcc_panel_update", obj.get_option("slots_per_stream"), N, args.precision)
             peak = FP64_MFMA_PEAK_TFLOPS if args.precision == "fp64" else FP32_MFMA_PEAK_TFLOPS
-            if args.precision != "fp64":
-                traffic, tsrc = None, None
             roofline = {"bound": "mfma", "kernel": "gpcc_panel_update", "achieved": round(achieved, 3),
                         "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                         "traffic": traffic, "traffic_source": tsrc, "launches": launches, "avg_launch_ms": round(avg_ms, 4),

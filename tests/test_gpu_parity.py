@@ -456,3 +456,31 @@ def test_device_pointer_api_matches_host_api(gp):
         side.synchronize()
         assert np.array_equal(out.cpu().numpy(), ref) and np.array_equal(info.cpu().numpy(), rinfo)
         np.testing.assert_allclose(prob.cpu().numpy(), gp.getprobabilities(ref), rtol=1e-12)
+
+
+def test_abi_misuse_is_reported_not_crashed(gp):
+    """Every entry point returns an error code + message for bad arguments (never throws across the boundary)."""
+    import ctypes
+
+    from gpcc_amd import _capi
+    lib = _capi.load()
+    h = ctypes.c_void_p()
+    Nl = (ctypes.c_int * 1)(3)
+    v = (ctypes.c_double * 3)(0.0, 1.0, 2.0)
+    assert lib.gpcc_create(ctypes.byref(h), 0, Nl, v, v, v, 0, 1, 0, 0) == -1 and "L=0" in _capi.last_error()
+    assert lib.gpcc_create(ctypes.byref(h), 1, Nl, v, v, v, 9, 1, 0, 0) == -1 and "kernel_id" in _capi.last_error()
+    assert lib.gpcc_create(ctypes.byref(h), 1, Nl, v, v, v, 0, 1, 7, 0) == -1 and "precision" in _capi.last_error()
+    assert lib.gpcc_create(ctypes.byref(h), 1, Nl, v, v, v, 0, 1, 0, 99) == -1 and "device_id" in _capi.last_error()
+    one = (ctypes.c_int * 1)(1)
+    assert lib.gpcc_create(ctypes.byref(h), 1, one, v, v, v, 0, 1, 0, 0) == -1      # var(y) undefined with n = 1
+    assert lib.gpcc_create(ctypes.byref(h), 1, Nl, v, v, v, 0, 1, 0, 0) == 0 and h.value
+    assert lib.gpcc_set_option(h, b"no_such_option", 1) == -1 and "unknown option" in _capi.last_error(h)
+    assert lib.gpcc_set_option(h, b"streams", 99) == -1
+    out = (ctypes.c_double * 1)()
+    info = (ctypes.c_int * 1)()
+    assert lib.gpcc_loglik_batch(h, -1, v, v, v, out, info) == -1
+    assert lib.gpcc_loglik_batch(h, 1, None, v, v, out, info) == -1 and "NULL" in _capi.last_error(h)
+    assert lib.gpcc_loglik_batch(None, 1, v, v, v, out, info) == -1
+    assert lib.gpcc_profile_get(h, 99, None, None) == -1
+    assert lib.gpcc_probabilities(0, v, None, v, 0) == -1
+    assert lib.gpcc_destroy(h) == 0 and lib.gpcc_destroy(None) == 0
