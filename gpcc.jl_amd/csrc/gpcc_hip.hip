@@ -30,7 +30,7 @@ struct gpcc_handle_s {
     std::vector<double> t_host, y_host, sig2_host;
     std::vector<int> band_host;
     // options
-    int streams = 1, slots_per_stream = 256, lds_dma = 1, diag_skip = 0, right_looking_max = GPCC_RIGHT_LOOKING_MAX;
+    int streams = 1, slots_per_stream = 256, lds_dma = 1, right_looking_max = GPCC_RIGHT_LOOKING_MAX;
     // workspace
     bool ws_ready = false;
     int ws_streams = 0, ws_slots = 0;
@@ -222,8 +222,6 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->slots_per_stream = (int)v;
     } else if (!strcmp(key, "lds_dma")) {
         h->lds_dma = v ? 1 : 0;
-    } else if (!strcmp(key, "diag_skip")) {
-        h->diag_skip = v ? 1 : 0;
     } else if (!strcmp(key, "right_looking_max")) {
         h->right_looking_max = (int)v;
     } else {
@@ -238,7 +236,6 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "streams")) return h->streams;
     if (!strcmp(key, "slots_per_stream")) return h->slots_per_stream;
     if (!strcmp(key, "lds_dma")) return h->lds_dma;
-    if (!strcmp(key, "diag_skip")) return h->diag_skip;
     if (!strcmp(key, "right_looking_max")) return h->right_looking_max;
     if (!strcmp(key, "N")) return h->N;
     if (!strcmp(key, "Np")) return h->Np;
@@ -261,12 +258,10 @@ static int set_kernel_attributes(gpcc_handle_t h)
 {
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_diag_factor<double>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_DIAG_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_diag_factor<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_DIAG_LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<double, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<double, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<double, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<float, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<float, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<float, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<double, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<double, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_trsm<double>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_trsm<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
     return 0;
@@ -309,7 +304,7 @@ static GpccCtx make_ctx(gpcc_handle_t h)
     c.slot_stride = h->slot_stride;
     c.L = h->L; c.N = h->N; c.Np = h->Np; c.nt = h->nt; c.kernel_id = h->kernel_id; c.marginalise_b = h->mb;
     c.nt_fact = h->nt;
-    c.nrhs = h->nrhs; c.woodbury = h->woodbury; c.diag_skip = h->diag_skip;
+    c.nrhs = h->nrhs; c.woodbury = h->woodbury;
     return c;
 }
 
@@ -364,8 +359,7 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
     for (int k = 0; k < c.nt_fact; ++k) {
         if (k > 0 && !right) {
             ProfScope p(h, GPCC_PROF_PANEL_UPDATE, s);
-            if (c.diag_skip) gpcc_panel_update<T, true, false><<<cnt8 * (c.nt - k), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, k);
-            else gpcc_panel_update<T, false, false><<<cnt8 * (c.nt - k), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, k);
+            gpcc_panel_update<T, false><<<cnt8 * (c.nt - k), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, k);
         }
         {
             ProfScope p(h, GPCC_PROF_DIAG, s);
@@ -378,13 +372,13 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
         if (right && k < c.nt - 1) {
             ProfScope p(h, GPCC_PROF_PANEL_UPDATE, s);
             const int n = c.nt - k - 1;
-            gpcc_panel_update<T, false, true><<<cnt8 * (n * (n + 1) / 2), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, 1);
+            gpcc_panel_update<T, true><<<cnt8 * (n * (n + 1) / 2), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, 1);
         }
     }
     // augmented systems: Schur complement of the rows beyond the factorised columns,
     // S = C - V^T V with V = L^-1 [cross block]  
     for (int k = c.nt_fact; k < c.nt; ++k)
-        gpcc_panel_update<T, false, false><<<cnt8 * (c.nt - k), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, c.nt_fact);
+        gpcc_panel_update<T, false><<<cnt8 * (c.nt - k), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, c.nt_fact);
 }
 
 // left-looking blocked Cholesky + fused forward solve (+ Schur complement of non-factorised rows)

@@ -74,7 +74,6 @@ struct GpccCtx {
     int L, N, Np, nt, kernel_id, marginalise_b;
     int nt_fact;   // tile columns that are factorised (== nt for the plain log-likelihood)
     int nrhs;      // 1: R = Y - bbar.  L+1 (woodbury): R = [Q | Y - bbar]
-    int diag_skip; // 1: skip the strictly-upper waves of diagonal tiles in gpcc_panel_update
     int woodbury;  // 1: the matrix is K0 = delayedCovariance + Sobs only; B = Q Sigma_b Q' enters through the
                    //    L x L capacitance matrix in fp64 (determinant lemma + Woodbury) -- the fp32 path
 };
@@ -298,8 +297,10 @@ __device__ __forceinline__ void gpcc_dma_chunk(const T *gA, const T *gB, T *stag
 // gpcc_panel_update (step k, tile I >= k):  T(I,k) -= sum_{j<ktiles} L(I,j) L(k,j)^T
 // = LAPACK dpotrf's dsyrk/dgemm (reached from cholesky(K), marginaliseb.jl:139), left-looking:
 // the K-loop runs over the chunks of the two contiguous tile rows I and k, the accumulator
-// starts at -T(I,k) and is stored back negated (no read-modify-write).  On the diagonal tile
-// (I == k, dsyrk) the two waves strictly above the diagonal skip their MFMAs.
+// starts at -T(I,k) and is stored back negated (no read-modify-write).  The diagonal tile (I == k, dsyrk) is
+// computed in full like the others (4.5 % of the update flops are redundant; letting the two waves strictly
+// above the diagonal skip their MFMAs bought nothing in an in-process A/B, nor did staggering the two
+// workgroups of a CU by half a chunk period).
 // Blocks of one evaluation share blockIdx % 8, i.e. (as dispatched) an XCD and its L2: they all
 // stream tile row k.
 // ------------------------------------------------------------------------------------------
@@ -308,7 +309,7 @@ __device__ __forceinline__ void gpcc_dma_chunk(const T *gA, const T *gB, T *stag
 // T(I,J) -= L(I,k) L(J,k)^T -- n(n+1)/2 short jobs (one tile of K) per evaluation instead of n long ones, so a
 // handful of matrices still fills the chip; it re-reads and re-writes the trailing matrix every step, which the
 // 256 MiB Infinity Cache absorbs for a few matrices but HBM would not for 256.
-template <typename T, bool SKIP, bool RIGHT>
+template <typename T, bool RIGHT>
 __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup g, int k, int ktiles)
 {
     typedef GpccPrec<T> P;
@@ -347,20 +348,14 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
 
     gpcc_dma_chunk<T>(gA, gB, smem, wave, lane);
 
-    // dsyrk tile (I == k): the two waves that own rows 0..63 x columns 64..127 lie strictly above the
-    // diagonal -- nobody reads that part -- so they only take part in the staging and the barriers
-    const bool skip = SKIP && (I == J) && (wc == 1) && (wr < 2);
-
     typename P::acc_t acc[2][4];
-    if (!skip) {
 #pragma unroll
-        for (int fm = 0; fm < 2; ++fm)
+    for (int fm = 0; fm < 2; ++fm)
 #pragma unroll
-            for (int fn = 0; fn < 4; ++fn)
+        for (int fn = 0; fn < 4; ++fn)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[fm][fn][r] = -Tt[gpcc_elem_off<T>(wr * 32 + fm * 16 + P::crow(q, r), wc * 64 + fn * 16 + lr)];
-    }
+            for (int r = 0; r < 4; ++r)
+                acc[fm][fn][r] = -Tt[gpcc_elem_off<T>(wr * 32 + fm * 16 + P::crow(q, r), wc * 64 + fn * 16 + lr)];
 
     // per-lane LDS addresses: one base per 16-byte slot, fragments/stages are immediates from it.
     // lane (lr, q) holds k = KSTEPS*q .. KSTEPS*q + KSTEPS-1 of its row: the MFMA sums over q, the steps over s
@@ -378,7 +373,6 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
             if (ch + 1 < nch)
                 gpcc_dma_chunk<T>(gA + (long)(ch + 1) * CH, gB + (long)(ch + 1) * CH, smem + (st ^ 1) * 2 * CH, wave, lane);
             const int so = st * 2 * CH;
-            if (!skip) {
             typename P::v16 a[2][2];
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
@@ -401,12 +395,10 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
                         for (int f = 0; f < 2; ++f)
                             acc[fm][2 * h + f] = P::mfma(a[fm][s / P::EP][s % P::EP], b[f][s / P::EP][s % P::EP], acc[fm][2 * h + f]);
             }
-            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
     }
-    if (skip) return;
 #pragma unroll
     for (int fm = 0; fm < 2; ++fm)
 #pragma unroll
