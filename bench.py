@@ -74,7 +74,6 @@ def main():
     ap.add_argument("--precision", default="fp64", choices=["fp64", "fp32"])
     ap.add_argument("--streams", type=int, default=None)
     ap.add_argument("--slots", type=int, default=None)
-    ap.add_argument("--lds-dma", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="oracle evaluations in the CPU baseline (0: one per core)")
@@ -114,7 +113,7 @@ def main():
     delays = np.stack([np.zeros(G), grid_all[lo:lo + G]], 1)
 
     obj = gpcc_amd.Objective(t, y, s, args.kernel, marginalise_b=True, precision=args.precision, device=local,
-                             streams=args.streams, slots_per_stream=args.slots, lds_dma=args.lds_dma)
+                             streams=args.streams, slots_per_stream=args.slots)
     d_delays = torch.as_tensor(delays, device=dev).contiguous()
     d_alpha = torch.as_tensor(np.tile(alpha, (G, 1)), device=dev).contiguous()
     d_rho = torch.full((G,), float(rho), dtype=torch.float64, device=dev)
@@ -221,7 +220,7 @@ def main():
             "config": {"workload": "2-band synthetic N=%d per band (N=%d), %s %s, %d-point delay grid per GPU"
                                    % (Nb, N, args.kernel, args.precision, G),
                        "grid_total": Gtot, "streams": obj.get_option("streams"),
-                       "slots_per_stream": obj.get_option("slots_per_stream"), "lds_dma": obj.get_option("lds_dma"),
+                       "slots_per_stream": obj.get_option("slots_per_stream"),
                        "parallelism": "grid-sharded x%d, 1 all_gather" % world},
             "info_nonzero": info_bad, "posterior_sum": psum,
             "roofline": roofline, "cpu_baseline": cpu_baseline,

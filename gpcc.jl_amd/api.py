@@ -141,7 +141,7 @@ class Objective:
     closure; a grid sweep varies it), so one handle serves a whole delay grid."""
 
     def __init__(self, tarray, yarray, stdarray, kernel, marginalise_b=True, precision="fp64", device=0,
-                 streams=None, slots_per_stream=None, lds_dma=None):
+                 streams=None, slots_per_stream=None):
         self._h = None
         self.kernel = _kernel(kernel)
         L = len(tarray)
@@ -158,7 +158,7 @@ class Objective:
         _capi.check(lib.gpcc_create(ctypes.byref(h), L, _ip(Nl), _dp(t), _dp(y), _dp(s), self.kernel.id,
                                     int(self.marginalise_b), _capi.PRECISION_IDS[precision], self.device))
         self._h = h
-        for key, val in (("streams", streams), ("slots_per_stream", slots_per_stream), ("lds_dma", lds_dma)):
+        for key, val in (("streams", streams), ("slots_per_stream", slots_per_stream)):
             if val is not None:
                 self.set_option(key, int(val))
 

@@ -30,7 +30,7 @@ struct gpcc_handle_s {
     std::vector<double> t_host, y_host, sig2_host;
     std::vector<int> band_host;
     // options
-    int streams = 1, slots_per_stream = 256, lds_dma = 1, right_looking_max = GPCC_RIGHT_LOOKING_MAX;
+    int streams = 1, slots_per_stream = 256, right_looking_max = GPCC_RIGHT_LOOKING_MAX;
     // workspace
     bool ws_ready = false;
     int ws_streams = 0, ws_slots = 0;
@@ -220,8 +220,6 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
     } else if (!strcmp(key, "slots_per_stream")) {
         if (v < 1 || v > 4096) return fail(h, GPCC_ERR_ARGUMENT, "slots_per_stream must be in [1,4096]");
         h->slots_per_stream = (int)v;
-    } else if (!strcmp(key, "lds_dma")) {
-        h->lds_dma = v ? 1 : 0;
     } else if (!strcmp(key, "right_looking_max")) {
         h->right_looking_max = (int)v;
     } else {
@@ -235,7 +233,6 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!h || !key) return -1;
     if (!strcmp(key, "streams")) return h->streams;
     if (!strcmp(key, "slots_per_stream")) return h->slots_per_stream;
-    if (!strcmp(key, "lds_dma")) return h->lds_dma;
     if (!strcmp(key, "right_looking_max")) return h->right_looking_max;
     if (!strcmp(key, "N")) return h->N;
     if (!strcmp(key, "Np")) return h->Np;

@@ -59,7 +59,9 @@ int gpcc_destroy(gpcc_handle_t handle);
 
 /* Tunables: "streams" (groups in flight on separate HIP streams, default 1), "slots_per_stream"
  * (evaluations resident per group, default 256 = one diagonal-block workgroup per CU, capped so
- * the workspace stays under 64 GiB); "lds_dma" is accepted for compatibility (always on). */
+ * the workspace stays under 64 GiB), "right_looking_max" (groups of at most this many evaluations use
+ * the right-looking update, default 24).  gpcc_get_option also answers "N", "Np", "precision",
+ * "bytes_per_slot". */
 int gpcc_set_option(gpcc_handle_t handle, const char *key, long value);
 long gpcc_get_option(gpcc_handle_t handle, const char *key);
 
