@@ -484,3 +484,27 @@ def test_abi_misuse_is_reported_not_crashed(gp):
     assert lib.gpcc_profile_get(h, 99, None, None) == -1
     assert lib.gpcc_probabilities(0, v, None, v, 0) == -1
     assert lib.gpcc_destroy(h) == 0 and lib.gpcc_destroy(None) == 0
+
+
+def test_hyperparameter_envelope(gp, oracle):
+    """The ranges a Nelder-Mead run visits (README.md:172 uses rhomax = 300): alpha 1e-2..1e2, rho 0.1..300.
+    fp64 keeps <= 1e-9 everywhere (observed 8e-12); fp32 (K0 in fp32, cond(K0) ~ alpha^2 N_eff / sigma^2) keeps the
+    1e-3 bar for alpha <= 10 (observed 7e-6) and reaches ~1e-3 at alpha ~ 100
+    (profiles/r01/accuracy_envelope_hyperparameters.log)."""
+    from gpcc_amd import synthetic
+    rng = np.random.default_rng(11)
+    t, y, s, _ = synthetic.simulate_lightcurves([330, 300], seed=3, gap_band=1)
+    M = 96
+    delays = np.stack([np.zeros(M), rng.random(M) * 20], 1)
+    alpha = 10.0 ** rng.uniform(-2, 2, (M, 2))
+    rho = 10.0 ** rng.uniform(-1, np.log10(300), M)
+    ref, rinfo = oracle.loglik_batch("matern32", t, y, s, delays, alpha, rho, True, nthreads=16)
+    with gp.Objective(t, y, s, gp.matern32) as obj:
+        ll, info = obj.loglik_batch(delays, alpha, rho)
+    assert np.array_equal(info == 0, rinfo == 0)
+    ok = rinfo == 0
+    assert _rel(ll[ok], ref[ok]) <= 1e-9
+    small = ok & (alpha.max(axis=1) <= 10.0)
+    with gp.Objective(t, y, s, gp.matern32, precision="fp32") as obj:
+        ll32, info32 = obj.loglik_batch(delays, alpha, rho)
+    assert (info32[small] == 0).all() and _rel(ll32[small], ref[small]) <= FP32_RTOL
