@@ -31,6 +31,9 @@ struct gpcc_handle_s {
     std::vector<int> band_host;
     // options
     int streams = 1, slots_per_stream = 256, right_looking_max = GPCC_RIGHT_LOOKING_MAX;
+    int shared_prefix = 1;   // 0 off, 1 auto (host-pointer API detects it), 2 the caller asserts it
+    int share_tiles = 0;     // tile rows wholly inside band 1
+    bool share_now = false;  // decision for the batch being enqueued
     // workspace
     bool ws_ready = false;
     int ws_streams = 0, ws_slots = 0;
@@ -123,6 +126,7 @@ extern "C" int gpcc_create(gpcc_handle_t *out, int L, const int *Nl, const doubl
     h->precision = precision;
     h->woodbury = (precision == GPCC_PRECISION_FP32 && marginalise_b) ? 1 : 0;
     h->nrhs = h->woodbury ? L + 1 : 1;
+    h->share_tiles = (L >= 2) ? Nl[0] / GPCC_TILE : 0;
     {   // default group size: 256 evaluations resident (one per CU in the diagonal step), capped at 64 GiB
         const double per_slot = ((double)h->nt * (h->nt + 1) / 2 + 1) * GPCC_TILE_ELEMS * (precision ? 4.0 : 8.0) + 16.0 * h->Np * (L + 1);
         long cap = (long)(64.0 * 1024 * 1024 * 1024 / per_slot);
@@ -222,6 +226,9 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->slots_per_stream = (int)v;
     } else if (!strcmp(key, "right_looking_max")) {
         h->right_looking_max = (int)v;
+    } else if (!strcmp(key, "shared_prefix")) {
+        if (v < 0 || v > 2) return fail(h, GPCC_ERR_ARGUMENT, "shared_prefix must be 0, 1 or 2");
+        h->shared_prefix = (int)v;
     } else {
         return fail(h, GPCC_ERR_ARGUMENT, "unknown option '%s'", key);
     }
@@ -234,6 +241,8 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "streams")) return h->streams;
     if (!strcmp(key, "slots_per_stream")) return h->slots_per_stream;
     if (!strcmp(key, "right_looking_max")) return h->right_looking_max;
+    if (!strcmp(key, "shared_prefix")) return h->shared_prefix;
+    if (!strcmp(key, "share_tiles")) return h->share_tiles;
     if (!strcmp(key, "N")) return h->N;
     if (!strcmp(key, "Np")) return h->Np;
     if (!strcmp(key, "bytes_per_slot")) return (long)(((long)h->nt * (h->nt + 1) / 2 + 1) * GPCC_TILE_ELEMS) * (h->precision ? 4 : 8) + 16L * h->Np * h->nrhs;
@@ -301,7 +310,7 @@ static GpccCtx make_ctx(gpcc_handle_t h)
     c.slot_stride = h->slot_stride;
     c.L = h->L; c.N = h->N; c.Np = h->Np; c.nt = h->nt; c.kernel_id = h->kernel_id; c.marginalise_b = h->mb;
     c.nt_fact = h->nt;
-    c.nrhs = h->nrhs; c.woodbury = h->woodbury;
+    c.nrhs = h->nrhs; c.woodbury = h->woodbury; c.share_p = 0;
     return c;
 }
 
@@ -352,22 +361,25 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
 {
     const int cnt8 = 8 * ((g.cnt + 7) / 8);
     // small groups (the single objective(alpha, rho) call): right-looking, many short jobs per step
-    const bool right = (g.cnt <= h->right_looking_max) && (c.nt_fact == c.nt);
+    const bool right = (g.cnt <= h->right_looking_max) && (c.nt_fact == c.nt) && !c.share_p;
+    const int p = c.share_p;   // shared prefix: steps k < p only involve the leader's rows < p and everyone's rows >= p
     for (int k = 0; k < c.nt_fact; ++k) {
         if (k > 0 && !right) {
-            ProfScope p(h, GPCC_PROF_PANEL_UPDATE, s);
-            gpcc_panel_update<T, false><<<cnt8 * (c.nt - k), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, k);
+            ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
+            const int grid = (k < p) ? cnt8 * (c.nt - p) + (p - k) : cnt8 * (c.nt - k);
+            gpcc_panel_update<T, false><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, k);
         }
         {
-            ProfScope p(h, GPCC_PROF_DIAG, s);
-            gpcc_diag_factor<T><<<g.cnt, 256, GPCC_DIAG_LDS_BYTES, s>>>(c, g, k);
+            ProfScope pr(h, GPCC_PROF_DIAG, s);
+            gpcc_diag_factor<T><<<(k < p) ? 1 : g.cnt, 256, GPCC_DIAG_LDS_BYTES, s>>>(c, g, k);
         }
         if (k < c.nt - 1) {
-            ProfScope p(h, GPCC_PROF_TRSM, s);
-            gpcc_panel_trsm<T><<<cnt8 * (c.nt - k - 1), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
+            ProfScope pr(h, GPCC_PROF_TRSM, s);
+            const int grid = (k < p) ? cnt8 * (c.nt - p) + (p - k - 1) : cnt8 * (c.nt - k - 1);
+            if (grid > 0) gpcc_panel_trsm<T><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
         }
         if (right && k < c.nt - 1) {
-            ProfScope p(h, GPCC_PROF_PANEL_UPDATE, s);
+            ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
             const int n = c.nt - k - 1;
             gpcc_panel_update<T, true><<<cnt8 * (n * (n + 1) / 2), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, 1);
         }
@@ -400,6 +412,7 @@ extern "C" int gpcc_loglik_batch_device(gpcc_handle_t h, int M, const double *d_
     rc = ensure_workspace(h);
     if (rc) return rc;
     hipStream_t caller = (hipStream_t)stream;
+    if (!h->share_now) h->share_now = (h->shared_prefix == 2);   // device pointers cannot be inspected: only on assertion
     const GpccCtx c = make_ctx(h);
     const int S = h->prof ? 1 : h->streams;  // profiling serialises groups onto one stream
     const int cs = h->slots_per_stream;
@@ -415,13 +428,17 @@ extern "C" int gpcc_loglik_batch_device(gpcc_handle_t h, int M, const double *d_
         g.first = gi * cs;
         g.slot0 = s * cs;
         g.cnt = (M - g.first < cs) ? (M - g.first) : cs;
-        rc = enqueue_group(h, c, g, h->str[s]);
+        GpccCtx cg = c;
+        if (h->share_now && h->share_tiles > 0 && h->share_tiles < h->nt && g.cnt > h->right_looking_max && g.cnt > 1)
+            cg.share_p = h->share_tiles;
+        rc = enqueue_group(h, cg, g, h->str[s]);
         if (rc) return rc;
     }
     for (int s = 0; s < used; ++s) {
         HIPCHK(h, hipEventRecord(h->ev_done[s], h->str[s]));
         HIPCHK(h, hipStreamWaitEvent(caller, h->ev_done[s], 0));
     }
+    h->share_now = false;
     return 0;
 }
 
@@ -453,7 +470,18 @@ extern "C" int gpcc_loglik_batch(gpcc_handle_t h, int M, const double *delays, c
     HIPCHK(h, hipMemcpyAsync(dd, delays, sizeof(double) * ML, hipMemcpyHostToDevice, h->main_stream));
     HIPCHK(h, hipMemcpyAsync(da, alpha, sizeof(double) * ML, hipMemcpyHostToDevice, h->main_stream));
     HIPCHK(h, hipMemcpyAsync(dr, rho, sizeof(double) * M, hipMemcpyHostToDevice, h->main_stream));
+    if (h->shared_prefix == 1 && M > 1 && h->share_tiles > 0) {
+        // fixed-hyper-parameter delay sweeps (README.md:172-174 with delays = [0; d]): every evaluation has the same
+        // band-1 amplitude, delay and rho, so the leading tile rows of K are identical within a group
+        bool same = rho[0] > 0.0;
+        for (int i = 0; i < M && same; ++i) {
+            same = alpha[(long)i * h->L] == alpha[0] && delays[(long)i * h->L] == delays[0] && rho[i] == rho[0];
+            for (int l = 0; l < h->L && same; ++l) same = alpha[(long)i * h->L + l] > 0.0;   // no argument errors in the batch
+        }
+        h->share_now = same;
+    }
     rc = gpcc_loglik_batch_device(h, M, dd, da, dr, h->d_out, h->d_oinfo, h->main_stream);
+    h->share_now = false;
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(loglik, h->d_out, sizeof(double) * M, hipMemcpyDeviceToHost, h->main_stream));
     HIPCHK(h, hipMemcpyAsync(info, h->d_oinfo, sizeof(int) * M, hipMemcpyDeviceToHost, h->main_stream));

@@ -74,6 +74,9 @@ struct GpccCtx {
     int L, N, Np, nt, kernel_id, marginalise_b;
     int nt_fact;   // tile columns that are factorised (== nt for the plain log-likelihood)
     int nrhs;      // 1: R = Y - bbar.  L+1 (woodbury): R = [Q | Y - bbar]
+    int share_p;   // > 0: the evaluations of a group share their first share_p tile rows (same band-1 alpha, rho, delay):
+                   //      only the group's first slot (the leader) assembles / factorises them, the others read its tiles,
+                   //      inv(L_kk) and W_k for k < share_p -- bitwise the same values they would have computed
     int woodbury;  // 1: the matrix is K0 = delayedCovariance + Sobs only; B = Q Sigma_b Q' enters through the
                    //    L x L capacitance matrix in fp64 (determinant lemma + Woodbury) -- the fp32 path
 };
@@ -189,6 +192,8 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
     const int I = blockIdx.x / c.nt, J = blockIdx.x % c.nt;
     if (J > I) return;
     const int m = blockIdx.y, slot = g.slot0 + m, tid = threadIdx.x;
+    const int first_row = (c.share_p && m > 0) ? c.share_p : 0;   // followers of a shared prefix skip the leader's rows
+    if (I < first_row) return;
     const double *delays = g.delays + (long)(g.first + m) * c.L;
     const double *alpha = g.alpha + (long)(g.first + m) * c.L;
     const GpccKernelConst kc = gpcc_kernel_const<KID>(g.rho[g.first + m]);
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
     __shared__ double syv[EXT ? GPCC_TILE : 1];   // fluxes of the tile's columns (explicit 'Y' rows only)
     if (tid < GPCC_MAXL) ssb[tid] = (tid < c.L) ? c.sigma_b[tid] : 0.0;
 
-    if (I == 0 && tid == 0) {  // per-slot state + the reference's argument checks
+    if (I == first_row && J == 0 && tid == 0) {  // per-slot state + the reference's argument checks
         int bad = 0;
         for (int l = 0; l < c.L; ++l)
             if (!(alpha[l] > 0.0)) bad = -1;  // delayedCovariance.jl:3
@@ -279,6 +284,15 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
 // Operands go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, the
 // 16 KiB chunk lands as a linear copy) into a 2-deep ring: 2 x (A 16 KiB + B 16 KiB) = 64 KiB.
 // ------------------------------------------------------------------------------------------
+// A follower of a shared prefix inherits the leader's failure only if it happened inside the prefix
+// (argument error, or a non-positive pivot among the first share_p*128 columns).
+__device__ __forceinline__ int gpcc_leader_failure(const GpccCtx &c, const GpccGroup &g)
+{
+    if (!c.share_p) return 0;
+    const int li = c.info[g.slot0];
+    return (li < 0 || (li > 0 && li <= c.share_p * GPCC_TILE)) ? li : 0;
+}
+
 template <typename T>
 __device__ __forceinline__ void gpcc_dma_chunk(const T *gA, const T *gB, T *stage, int wave, int lane)
 {
@@ -321,12 +335,22 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
     const int sw = gpcc_sw(lr);
 
     const int nrem = c.nt - k - 1;
-    const int per = RIGHT ? nrem * (nrem + 1) / 2 : c.nt - k;
+    const bool shared = !RIGHT && c.share_p > k;   // step inside the shared prefix: B operand = the leader's row k
+    const int per = RIGHT ? nrem * (nrem + 1) / 2 : (shared ? c.nt - c.share_p : c.nt - k);
+    const int nmain = 8 * ((g.cnt + 7) / 8) * per;
     const int x = blockIdx.x & 7, qq = blockIdx.x >> 3;
-    const int m = (qq / per) * 8 + x;
-    if (m >= g.cnt) return;
+    int m = (qq / per) * 8 + x;
     int I, J;   // output tile (I,J); left-looking: J = k
-    if (RIGHT) {
+    if (shared && (int)blockIdx.x >= nmain) {   // the leader's own rows k .. share_p-1
+        m = 0;
+        I = k + ((int)blockIdx.x - nmain);
+        J = k;
+    } else if (m >= g.cnt) {
+        return;
+    } else if (shared) {
+        I = c.share_p + qq % per;
+        J = k;
+    } else if (RIGHT) {
         const int j = qq % per;
         int a = (int)((sqrtf(8.0f * j + 1.0f) - 1.0f) * 0.5f);
         while (a * (a + 1) / 2 > j) --a;
@@ -338,11 +362,12 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
         J = k;
     }
     const int slot = g.slot0 + m;
-    if (c.info[slot] != 0) return;
+    if (c.info[slot] != 0 || gpcc_leader_failure(c, g) != 0) return;
 
     T *tiles = (T *)c.tiles + (long)slot * c.slot_stride;
+    const T *btiles = shared ? (const T *)c.tiles + (long)g.slot0 * c.slot_stride : tiles;
     const T *gA = tiles + gpcc_tile_off(I, RIGHT ? k : 0);
-    const T *gB = tiles + gpcc_tile_off(J, RIGHT ? k : 0);
+    const T *gB = btiles + gpcc_tile_off(J, RIGHT ? k : 0);
     T *Tt = tiles + gpcc_tile_off(I, J);
     const int nch = P::NCH * ktiles;  // ktiles = k (left-looking), 1 (right-looking), or nt_fact (Schur complement)
 
@@ -426,18 +451,27 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_trsm(GpccCtx c, GpccGroup g
     const int lr = lane & 15, q = lane >> 4;
     const int sw = gpcc_sw(lr);
 
-    const int per = c.nt - k - 1;
+    const bool shared = c.share_p > k;   // inv(L_kk) and W_k of the shared prefix come from the leader
+    const int per = shared ? c.nt - c.share_p : c.nt - k - 1;
+    const int nmain = 8 * ((g.cnt + 7) / 8) * per;
     const int x = blockIdx.x & 7, qq = blockIdx.x >> 3;
-    const int m = (qq / per) * 8 + x;
-    if (m >= g.cnt) return;
-    const int I = k + 1 + qq % per;
+    int m = (qq / per) * 8 + x, I;
+    if (shared && (int)blockIdx.x >= nmain) {   // the leader's own rows k+1 .. share_p-1
+        m = 0;
+        I = k + 1 + ((int)blockIdx.x - nmain);
+    } else if (m >= g.cnt) {
+        return;
+    } else {
+        I = (shared ? c.share_p : k + 1) + qq % per;
+    }
     const int slot = g.slot0 + m;
-    if (c.info[slot] != 0) return;
+    const int lslot = shared ? g.slot0 : slot;
+    if (c.info[slot] != 0 || gpcc_leader_failure(c, g) != 0) return;
 
     T *tiles = (T *)c.tiles + (long)slot * c.slot_stride;
     T *Tt = tiles + gpcc_tile_off(I, k);
-    const T *gA = Tt;                                               // the chunks of T(I,k), overwritten at the end
-    const T *gB = (const T *)c.linv + (long)slot * GPCC_TILE_ELEMS;  // inv(L_kk): rows = output column, k = j
+    const T *gA = Tt;                                                // the chunks of T(I,k), overwritten at the end
+    const T *gB = (const T *)c.linv + (long)lslot * GPCC_TILE_ELEMS;  // inv(L_kk): rows = output column, k = j
 
     gpcc_dma_chunk<T>(gA, gB, smem, wave, lane);
     typename P::acc_t acc[8];
@@ -486,7 +520,7 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_trsm(GpccCtx c, GpccGroup g
         for (int fn = 0; fn < 8; ++fn) Tt[gpcc_elem_off<T>(wave * 16 + P::crow(q, r), fn * 16 + lr)] = acc[fn][r];
     for (int j = 0; j < c.nrhs; ++j) {
         double *zp = c.z + ((long)slot * c.nrhs + j) * c.Np + I * GPCC_TILE;
-        const double *wp = c.w + ((long)slot * c.nrhs + j) * c.Np + k * GPCC_TILE;
+        const double *wp = c.w + ((long)lslot * c.nrhs + j) * c.Np + k * GPCC_TILE;
         double wv[8];
 #pragma unroll
         for (int fn = 0; fn < 8; ++fn) wv[fn] = wp[fn * 16 + lr];
@@ -542,7 +576,8 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, q = lane >> 4;
     const int m = blockIdx.x, slot = g.slot0 + m, nrhs = c.nrhs;
     const bool last = (k == c.nt_fact - 1);
-    const int inf = c.info[slot];
+    int inf = c.info[slot];
+    if (inf == 0 && m > 0) inf = gpcc_leader_failure(c, g);   // a failed shared prefix fails its followers too
     if (inf != 0) {
         if (last && tid == 0) {
             g.out_loglik[g.first + m] = __builtin_nan("");
@@ -692,6 +727,17 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
         sG[tid] = s;
     }
     __syncthreads();
+    if (c.share_p && k == c.share_p - 1) {
+        // last step of the shared prefix (only the leader runs it): hand sum log L_ii and W'W over to the followers
+        double ldp = 0.0;   // same summation order as the per-evaluation path below (bitwise identical results)
+        for (int i = 0; i < GPCC_TILE; ++i) ldp += sr[i];
+        ldp += c.logdet[slot];
+        for (int f = 1 + tid; f < g.cnt; f += 256) {
+            c.logdet[g.slot0 + f] = ldp;
+            for (int i = 0; i < nrhs * nrhs; ++i) c.gram[(long)(g.slot0 + f) * GPCC_MAXRHS * GPCC_MAXRHS + i] = sG[i];
+        }
+        __syncthreads();   // everybody has read the leader's running sum before thread 0 updates it below
+    }
     if (tid == 0) {
         double ld = 0.0;
         for (int i = 0; i < GPCC_TILE; ++i) ld += sr[i];

@@ -60,8 +60,11 @@ int gpcc_destroy(gpcc_handle_t handle);
 /* Tunables: "streams" (groups in flight on separate HIP streams, default 1), "slots_per_stream"
  * (evaluations resident per group, default 256 = one diagonal-block workgroup per CU, capped so
  * the workspace stays under 64 GiB), "right_looking_max" (groups of at most this many evaluations use
- * the right-looking update, default 24).  gpcc_get_option also answers "N", "Np", "precision",
- * "bytes_per_slot". */
+ * the right-looking update, default 24), "shared_prefix" (0 off; 1 = default: gpcc_loglik_batch detects a
+ * batch whose evaluations all have the same band-1 amplitude, delay and rho -- a fixed-hyper-parameter delay
+ * sweep, README.md:172-174 -- and then factorises the tile rows wholly inside band 1 once per group instead of
+ * once per evaluation, results bitwise identical; 2 = the caller asserts that property, also for the _device
+ * form).  gpcc_get_option also answers "N", "Np", "precision", "bytes_per_slot", "share_tiles". */
 int gpcc_set_option(gpcc_handle_t handle, const char *key, long value);
 long gpcc_get_option(gpcc_handle_t handle, const char *key);
 

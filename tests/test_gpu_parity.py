@@ -508,3 +508,52 @@ def test_hyperparameter_envelope(gp, oracle):
     with gp.Objective(t, y, s, gp.matern32, precision="fp32") as obj:
         ll32, info32 = obj.loglik_batch(delays, alpha, rho)
     assert (info32[small] == 0).all() and _rel(ll32[small], ref[small]) <= FP32_RTOL
+
+
+# ---- section 8(f).4: evaluations of a group that share band 1's (alpha, rho, delay) reuse the leader's leading tile rows
+@pytest.mark.parametrize("Nl,prec", [([300, 280], "fp64"), ([2048, 2048], "fp64"), ([260, 200, 190], "fp64"), ([384, 300], "fp32")])
+def test_shared_prefix_is_bitwise_identical(gp, Nl, prec):
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves(Nl, seed=7)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    L = len(Nl)
+    M = 70                                         # two groups of 40: 40 and 30 evaluations (> right_looking_max)
+    rng = np.random.default_rng(5)
+    delays = np.concatenate([np.zeros((M, 1)), rng.random((M, L - 1)) * 15], 1)
+    alphas = np.tile(alpha, (M, 1))
+    alphas[:, 1:] *= 0.6 + 0.8 * rng.random((M, L - 1))      # the other bands' amplitudes differ per evaluation
+    rhos = np.full(M, rho)
+    with gp.Objective(t, y, s, gp.matern32, precision=prec, slots_per_stream=40) as obj:
+        assert obj.get_option("share_tiles") == Nl[0] // 128
+        obj.set_option("shared_prefix", 0)
+        ref, rinfo = obj.loglik_batch(delays, alphas, rhos)
+        obj.set_option("shared_prefix", 1)         # auto: the host-pointer API sees identical band-1 parameters
+        ll, info = obj.loglik_batch(delays, alphas, rhos)
+        assert (rinfo == 0).all() and np.array_equal(info, rinfo) and np.array_equal(ll, ref)
+        # not shareable (band-1 delay differs): auto mode must fall back to the plain path
+        d2 = delays.copy()
+        d2[3, 0] = 0.25
+        a, ia = obj.loglik_batch(d2, alphas, rhos)
+        obj.set_option("shared_prefix", 0)
+        b, ib = obj.loglik_batch(d2, alphas, rhos)
+        assert np.array_equal(a, b) and np.array_equal(ia, ib)
+
+
+def test_shared_prefix_failure_inside_prefix(gp):
+    """A non-positive pivot inside the shared rows (duplicate times in band 1, sigma = 0, fixed-b variant) is
+    reported for every evaluation exactly as without sharing."""
+    rng = np.random.default_rng(2)
+    t0 = rng.random(300) * 50
+    t0[17] = t0[5]                                 # duplicate time -> singular K0 with sigma = 0
+    t = [t0, rng.random(200) * 50]
+    y = [rng.standard_normal(300), rng.standard_normal(200)]
+    s = [np.zeros(300), np.full(200, 0.3)]
+    M = 30
+    delays = np.stack([np.zeros(M), np.linspace(0, 5, M)], 1)
+    alphas, rhos = np.tile([1.0, 1.3], (M, 1)), np.full(M, 2.0)
+    with gp.Objective(t, y, s, gp.OU, marginalise_b=False, slots_per_stream=32) as obj:
+        obj.set_option("shared_prefix", 0)
+        ref, rinfo = obj.loglik_batch(delays, alphas, rhos)
+        obj.set_option("shared_prefix", 1)
+        ll, info = obj.loglik_batch(delays, alphas, rhos)
+    assert (rinfo > 0).all() and np.array_equal(info, rinfo) and np.isnan(ll).all()
