@@ -248,6 +248,7 @@ def main():
         print(json.dumps(out))
     obj.close()
     if world > 1:
+        dist.barrier()     # rank 0 is the last to arrive (roofline leg): leave the group together
         dist.destroy_process_group()
 
 
