@@ -557,3 +557,36 @@ def test_shared_prefix_failure_inside_prefix(gp):
         obj.set_option("shared_prefix", 1)
         ll, info = obj.loglik_batch(delays, alphas, rhos)
     assert (rinfo > 0).all() and np.array_equal(info, rinfo) and np.isnan(ll).all()
+
+
+def test_randomised_differential_vs_oracle(gp, oracle):
+    """60 random problems (1-4 bands, ragged sizes down to 1-2 points per band, all kernels, both b-modes, random
+    batch sizes that cross the right-looking / left-looking / shared-prefix switches) against the oracle."""
+    rng = np.random.default_rng(20240918)
+    knames = ["OU", "rbf", "matern32", "matern52"]
+    worst = 0.0
+    for trial in range(60):
+        L = int(rng.integers(1, 5))
+        mb = bool(rng.integers(0, 2))
+        lo = 2 if mb else 1
+        Nl = [int(rng.integers(lo, 40)) if rng.random() < 0.3 else int(rng.integers(lo, 330)) for _ in range(L)]
+        t = [rng.random(n) * rng.uniform(5, 60) for n in Nl]
+        y = [rng.uniform(-5, 30) + rng.uniform(0.2, 3) * np.sin(0.2 * t[l] + l) + rng.standard_normal(Nl[l]) * 0.4
+             for l in range(L)]
+        s = [rng.uniform(0.05, 1.0, n) for n in Nl]
+        kname = knames[int(rng.integers(0, 4))]
+        M = int(rng.choice([1, 3, 25, 40]))
+        delays = rng.uniform(-5, 20, (M, L))
+        alpha = 10.0 ** rng.uniform(-1, 1, (M, L))
+        rho = 10.0 ** rng.uniform(-0.7, 1.7, M)
+        if M >= 25 and rng.random() < 0.5:          # make the batch shareable: same band-1 parameters
+            delays[:, 0], alpha[:, 0], rho[:] = delays[0, 0], alpha[0, 0], rho[0]
+        ref, rinfo = oracle.loglik_batch(kname, t, y, s, delays, alpha, rho, mb, nthreads=8)
+        with gp.Objective(t, y, s, kname, marginalise_b=mb, slots_per_stream=32) as obj:
+            ll, info = obj.loglik_batch(delays, alpha, rho)
+        ok = rinfo == 0
+        assert np.array_equal(info == 0, ok), (trial, Nl, kname, mb, info, rinfo)
+        if ok.any():
+            worst = max(worst, _rel(ll[ok], ref[ok]))
+    print("randomised differential test: worst relative error %.3e" % worst)
+    assert worst <= LL_RTOL
