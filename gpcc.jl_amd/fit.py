@@ -151,3 +151,10 @@ def gpcc(tarray, yarray, stdarray, *, kernel, delays, iterations, seed=1, number
     alpha, rho = res.alpha[0], float(res.rho[0])
     postb = obj.posterior_offsets(delays, alpha, rho)
     return float(res.loglikel[0]), Predictor(obj, delays, alpha, rho), (alpha, postb, rho)
+
+
+def singlegp(tobs, yobs, sigmaobs, *, kernel, iterations, seed=1, numberofrestarts=1, initialrandom=5, rhomin=0.1,
+             rhomax, device=0):
+    """src/util.jl:95-99: one band, delay [0.0] -- gpccfixdelay([tobs], [yobs], [sigmaobs]; tau = [0.0], ...)."""
+    return gpcc([tobs], [yobs], [sigmaobs], kernel=kernel, delays=[0.0], iterations=iterations, seed=seed,
+                numberofrestarts=numberofrestarts, initialrandom=initialrandom, rhomin=rhomin, rhomax=rhomax, device=device)
