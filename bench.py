@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", type=int, default=1024, help="delays per GPU per step")
     ap.add_argument("--n-per-band", type=int, default=2048)
+    ap.add_argument("--bands", type=int, default=2, help="2 (default metric config) or 3 (cfg4: 2-D delay grid)")
     ap.add_argument("--kernel", default="matern32")
     ap.add_argument("--precision", default="fp64", choices=["fp64", "fp32"])
     ap.add_argument("--streams", type=int, default=None)
@@ -103,14 +104,22 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     Nb = args.n_per_band
-    t, y, s, _ = synthetic.simulate_lightcurves([Nb, Nb], seed=1)
+    L = args.bands
+    t, y, s, _ = synthetic.simulate_lightcurves([Nb] * L, seed=1)
     alpha, rho = synthetic.default_hyperparameters(y)
-    N = 2 * Nb
+    N = L * Nb
     G = args.grid
     Gtot = G * world
-    grid_all = np.linspace(0.0, 20.0, Gtot)
     lo = rank * G
-    delays = np.stack([np.zeros(G), grid_all[lo:lo + G]], 1)
+    if L == 2:
+        grid_all = np.linspace(0.0, 20.0, Gtot)
+        delays = np.stack([np.zeros(G), grid_all[lo:lo + G]], 1)
+    else:   # cfg4: (tau_2, tau_3) on a square grid over [0.5, 6]^2 (README.md:227), flattened row-major
+        side = int(np.ceil(np.sqrt(Gtot)))
+        g1 = np.linspace(0.5, 6.0, side)
+        d2, d3 = np.meshgrid(g1, g1, indexing="ij")
+        flat = np.stack([np.zeros(side * side), d2.ravel(), d3.ravel()], 1)[:Gtot]
+        delays = np.ascontiguousarray(flat[lo:lo + G])
 
     obj = gpcc_amd.Objective(t, y, s, args.kernel, marginalise_b=True, precision=args.precision, device=local,
                              streams=args.streams, slots_per_stream=args.slots)
@@ -237,8 +246,8 @@ def main():
             "value": round(value, 2), "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64" if args.precision == "fp64" else "f32", "data": "synthetic",
-            "config": {"workload": "2-band synthetic N=%d per band (N=%d), %s %s, %d-point delay grid per GPU"
-                                   % (Nb, N, args.kernel, args.precision, G),
+            "config": {"workload": "%d-band synthetic N=%d per band (N=%d), %s %s, %d-point delay grid per GPU"
+                                   % (L, Nb, N, args.kernel, args.precision, G),
                        "grid_total": Gtot, "streams": obj.get_option("streams"),
                        "slots_per_stream": obj.get_option("slots_per_stream"),
                        "parallelism": "grid-sharded x%d, 1 all_gather" % world},
