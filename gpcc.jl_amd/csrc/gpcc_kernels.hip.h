@@ -185,6 +185,8 @@ __device__ __forceinline__ double gpcc_kernel_eval(double xi, double xj, GpccKer
 // and the right-hand sides are [Q | Y - bbar].
 // grid (nt*nt, cnt), block 256.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool diag_tile(int I, int J) { return I == J; }
+
 template <int KID, bool EXT, typename T>
 __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup g)
 {
@@ -237,6 +239,31 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
     const bool diag = (I == J);
     const bool mb = c.marginalise_b != 0 && !c.woodbury;
     const int sp = tid & 7;  // this thread's 16-byte storage slot in every row it writes
+    // Points are ordered by band (padding / explicit rows last), so a tile whose first and last row (column) carry
+    // the same band id >= 0 lies inside one band pair: no diagonal, no padding, a uniform B term -- the plain
+    // element (scale_i scale_j kernel + const) without any per-element select.  Most tiles are of this kind.
+    const int rb0 = sb[0][0], cb0 = sb[1][0];
+    if (!diag_tile(I, J) && rb0 >= 0 && cb0 >= 0 && rb0 == sb[0][GPCC_TILE - 1] && cb0 == sb[1][GPCC_TILE - 1]) {
+        const double bt = (c.marginalise_b != 0 && !c.woodbury && rb0 == cb0) ? ssb[rb0] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (tid >> 3) + 32 * j;
+            const double ur = su[0][r], ar = sa[0][r];
+            const int cs = (sp ^ gpcc_sw(r)) * P::EP;
+#pragma unroll
+            for (int ch = 0; ch < P::NCH; ++ch) {
+                const int col = ch * P::KC + cs;
+                typename P::v16 v;
+#pragma unroll
+                for (int h = 0; h < P::EP; ++h) {
+                    const double kv = gpcc_kernel_eval<KID>(ur, su[1][col + h], kc);
+                    v[h] = (T)((ar * sa[1][col + h]) * kv + bt);   // same operations as the general path below
+                }
+                *(typename P::v16 *)(Tt + ch * (GPCC_TILE * P::KC) + r * P::KC + sp * P::EP) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = (tid >> 3) + 32 * j;  // row data stays in registers across the chunks
