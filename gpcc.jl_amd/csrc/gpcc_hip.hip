@@ -310,7 +310,7 @@ static GpccCtx make_ctx(gpcc_handle_t h)
     c.slot_stride = h->slot_stride;
     c.L = h->L; c.N = h->N; c.Np = h->Np; c.nt = h->nt; c.kernel_id = h->kernel_id; c.marginalise_b = h->mb;
     c.nt_fact = h->nt;
-    c.nrhs = h->nrhs; c.woodbury = h->woodbury; c.share_p = 0;
+    c.nrhs = h->nrhs; c.woodbury = h->woodbury; c.share_p = 0; c.store_l = 0;
     return c;
 }
 
@@ -552,6 +552,7 @@ static int run_augmented(gpcc_handle_t h, const double *delays, const double *al
     c.logdet = c.w + Npa; c.gram = c.logdet + 1; c.info = a.d_info;
     c.slot_stride = stride; c.Np = Npa; c.nt = nta; c.nt_fact = h->nt; c.marginalise_b = marginalise_b;
     c.nrhs = 1; c.woodbury = 0;   // the dense utilities always run the literal fp64 model
+    c.store_l = 1;
     if (!marginalise_b) for (int l = 0; l < GPCC_MAXL; ++l) c.sigma_b[l] = 0.0;
     hipStream_t s = h->main_stream;
     double *dd = h->d_par, *da = h->d_par + h->L, *dr = h->d_par + 2 * h->L;

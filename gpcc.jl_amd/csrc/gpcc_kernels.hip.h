@@ -77,6 +77,7 @@ struct GpccCtx {
     int share_p;   // > 0: the evaluations of a group share their first share_p tile rows (same band-1 alpha, rho, delay):
                    //      only the group's first slot (the leader) assembles / factorises them, the others read its tiles,
                    //      inv(L_kk) and W_k for k < share_p -- bitwise the same values they would have computed
+    int store_l;   // gpcc_diag_factor also writes L_kk back (dense factor export); 0 on the log-likelihood path
     int woodbury;  // 1: the matrix is K0 = delayedCovariance + Sobs only; B = Q Sigma_b Q' enters through the
                    //    L x L capacitance matrix in fp64 (determinant lemma + Woodbury) -- the fp32 path
 };
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
             lv = sT[r * LD + col];
         }
         Linv[e] = (T)xv;
-        Tt[e] = (T)lv;
+        if (c.store_l) Tt[e] = (T)lv;   // L_kk itself is read by nobody on the log-likelihood path (only by the dense export)
     }
 }
 
