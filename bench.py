@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--slots", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--shared-extra", action="store_true",
+                    help="also time the sweep with the shared-prefix mode asserted (reported separately, never as `value`)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="oracle evaluations in the CPU baseline (0: one per core)")
     args = ap.parse_args()
 
@@ -172,7 +174,7 @@ def main():
     # same band-1 amplitude, delay and rho, so each group factorises the leading band-1 tile rows once; results are
     # bitwise identical).  `value` above is measured with every evaluation doing all of its own work.
     shared = None
-    if world == 1 and not args.no_roofline:
+    if world == 1 and args.shared_extra:
         obj.set_option("shared_prefix", 2)
         step(); fence()
         ll_shared = d_ll.clone()
