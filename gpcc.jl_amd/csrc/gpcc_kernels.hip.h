@@ -615,10 +615,20 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
     }
     T *tiles = (T *)c.tiles + (long)slot * c.slot_stride;
     T *Tt = tiles + gpcc_tile_off(k, k);
-    for (int e = tid; e < GPCC_TILE_ELEMS; e += 256) {  // e = storage position: consecutive threads, consecutive elements
-        const int ch = e / (GPCC_TILE * P::KC), rem = e % (GPCC_TILE * P::KC), r = rem / P::KC, ks = rem % P::KC;
-        const int kk = (((ks / P::EP) ^ gpcc_sw(r)) * P::EP) + (ks % P::EP);
-        sT[r * LD + ch * P::KC + kk] = (double)Tt[e];
+    // 16-byte pieces, 8 loads in flight per thread (one load per iteration would serialise 64 HBM round trips)
+    constexpr int NPIECE = GPCC_TILE_ELEMS / P::EP;   // pieces per tile
+    for (int p0 = tid; p0 < NPIECE; p0 += 256 * 8) {
+        typename P::v16 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *(const typename P::v16 *)(Tt + (long)(p0 + 256 * u) * P::EP);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = (p0 + 256 * u) * P::EP;   // storage position of the piece's first element
+            const int ch = e / (GPCC_TILE * P::KC), rem = e % (GPCC_TILE * P::KC), r = rem / P::KC, ks = rem % P::KC;
+            const int kk = ((ks / P::EP) ^ gpcc_sw(r)) * P::EP;
+#pragma unroll
+            for (int h = 0; h < P::EP; ++h) sT[r * LD + ch * P::KC + kk + h] = (double)v[u][h];
+        }
     }
     for (int e = tid; e < nrhs * GPCC_TILE; e += 256)
         sz[e] = c.z[((long)slot * nrhs + e / GPCC_TILE) * c.Np + k * GPCC_TILE + (e % GPCC_TILE)];
@@ -810,16 +820,24 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
     }
     // ---- write inv(L_kk) (B operand of the panel solve) and L_kk, both in tile layout
     T *Linv = (T *)c.linv + (long)slot * GPCC_TILE_ELEMS;
-    for (int e = tid; e < GPCC_TILE_ELEMS; e += 256) {
+    for (int p0 = tid; p0 < NPIECE; p0 += 256) {   // 16-byte stores
+        const int e = p0 * P::EP;
         const int ch = e / (GPCC_TILE * P::KC), rem = e % (GPCC_TILE * P::KC), r = rem / P::KC, ks = rem % P::KC;
-        const int col = ch * P::KC + (((ks / P::EP) ^ gpcc_sw(r)) * P::EP) + (ks % P::EP);
-        double xv = 0.0, lv = 0.0;
-        if (col <= r) {
-            xv = ((col >> 4) == (r >> 4)) ? sDinv[r * DLD + (col & 15)] : sT[col * LD + r];
-            lv = sT[r * LD + col];
+        const int col0 = ch * P::KC + ((ks / P::EP) ^ gpcc_sw(r)) * P::EP;
+        typename P::v16 xo, lo;
+#pragma unroll
+        for (int h = 0; h < P::EP; ++h) {
+            const int col = col0 + h;
+            double xv = 0.0, lv = 0.0;
+            if (col <= r) {
+                xv = ((col >> 4) == (r >> 4)) ? sDinv[r * DLD + (col & 15)] : sT[col * LD + r];
+                lv = sT[r * LD + col];
+            }
+            xo[h] = (T)xv;
+            lo[h] = (T)lv;
         }
-        Linv[e] = (T)xv;
-        if (c.store_l) Tt[e] = (T)lv;   // L_kk itself is read by nobody on the log-likelihood path (only by the dense export)
+        *(typename P::v16 *)(Linv + e) = xo;
+        if (c.store_l) *(typename P::v16 *)(Tt + e) = lo;   // L_kk is read by nobody on the log-likelihood path (dense export only)
     }
 }
 
