@@ -736,13 +736,24 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
     double wi[GPCC_MAXRHS];
 #pragma unroll
     for (int j = 0; j < GPCC_MAXRHS; ++j) wi[j] = 0.0;
-    if (tid < GPCC_TILE) {
-        const int bi = tid >> 4;
-        for (int cc = 0; cc <= tid; ++cc) {
-            const double xv = (cc < bi * 16) ? sT[cc * LD + tid] : sDinv[(bi * 16 + (tid & 15)) * DLD + (cc & 15)];
+    if (tid < GPCC_TILE) {   // row tid of X: off-diagonal blocks from the transposed image, then its diagonal block
+        const int bi = tid >> 4, li = tid & 15;
+        for (int cb = 0; cb < bi; ++cb) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {   // 16 independent LDS reads in flight
+                const int cc = cb * 16 + u;
+                const double xv = sT[cc * LD + tid];
+#pragma unroll
+                for (int j = 0; j < GPCC_MAXRHS; ++j)
+                    if (j < nrhs) wi[j] += xv * sz[j * GPCC_TILE + cc];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const double xv = (u <= li) ? sDinv[(bi * 16 + li) * DLD + u] : 0.0;
 #pragma unroll
             for (int j = 0; j < GPCC_MAXRHS; ++j)
-                if (j < nrhs) wi[j] += xv * sz[j * GPCC_TILE + cc];
+                if (j < nrhs && u <= li) wi[j] += xv * sz[j * GPCC_TILE + bi * 16 + u];
         }
     }
     __syncthreads();
