@@ -549,9 +549,11 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_trsm(GpccCtx c, GpccGroup g
     for (int j = 0; j < c.nrhs; ++j) {
         double *zp = c.z + ((long)slot * c.nrhs + j) * c.Np + I * GPCC_TILE;
         const double *wp = c.w + ((long)lslot * c.nrhs + j) * c.Np + k * GPCC_TILE;
-        double wv[8];
+        double wv[8], zold[4];
 #pragma unroll
         for (int fn = 0; fn < 8; ++fn) wv[fn] = wp[fn * 16 + lr];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zold[r] = zp[wave * 16 + P::crow(q, r)];   // all loads first: one round trip, not four
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int R = wave * 16 + P::crow(q, r);
@@ -562,7 +564,7 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_trsm(GpccCtx c, GpccGroup g
             p += __shfl_xor(p, 2);
             p += __shfl_xor(p, 4);
             p += __shfl_xor(p, 8);
-            if (lr == 0) zp[R] = zp[R] - p;
+            if (lr == 0) zp[R] = zold[r] - p;
         }
     }
 }
