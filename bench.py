@@ -86,11 +86,13 @@ def main():
     import torch.distributed as dist
 
     import gpcc_amd
+    from gpcc_amd import build as gbuild
     from gpcc_amd import synthetic
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    gbuild.ensure_present(local)     # source-only checkout: compile libgpcc_hip.so once per node (hipcc, gfx950)
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     ndev = torch.cuda.device_count()

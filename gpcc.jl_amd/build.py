@@ -24,14 +24,34 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
+    tmp = "%s.tmp%d" % (LIB_PATH, os.getpid())      # link elsewhere, then rename: no reader ever sees a partial file
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           "-o", LIB_PATH, os.path.join(CSRC, "gpcc_hip.hip")]
+           "-o", tmp, os.path.join(CSRC, "gpcc_hip.hip")]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode:
         print(" ".join(cmd))
         print(res.stdout, res.stderr)
     if res.returncode:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("hipcc failed:\n" + res.stderr)
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+def ensure_present(local_rank=0, timeout_s=900.0):
+    """For launchers that start one process per GPU from a source-only checkout: local rank 0 compiles the
+    library if the file is absent, the other ranks wait for it to appear.  Never rebuilds an existing file."""
+    import time
+    if os.path.exists(LIB_PATH):
+        return LIB_PATH
+    if local_rank == 0:
+        return build(force=True)
+    t0 = time.time()
+    while not os.path.exists(LIB_PATH):
+        if time.time() - t0 > timeout_s:
+            raise RuntimeError("%s did not appear within %.0f s" % (LIB_PATH, timeout_s))
+        time.sleep(1.0)
     return LIB_PATH
 
 

@@ -39,6 +39,34 @@ def invtransformbetween(y, a, b):
     return np.log(u) - np.log1p(-u)
 
 
+def nearestposdef(A, minimumeigenvalue=1e-6):
+    """MiscUtil.nearestposdef(A; minimumeigenvalue) as used at marginaliseb.jl:331 -- MiscUtil's source is not
+    available (unregistered dependency), so this is the assumed definition: symmetrise, eigendecompose, lift every
+    eigenvalue below `minimumeigenvalue` up to it, recompose, symmetrise.  Host-side like the reference's (it only
+    runs after a PosDefException on an Ntest x Ntest predictive covariance, never on the delay-grid path)."""
+    A = np.asarray(A, dtype=np.float64)
+    S = 0.5 * (A + A.T)
+    w, V = np.linalg.eigh(S)
+    R = (V * np.maximum(w, minimumeigenvalue)) @ V.T
+    return 0.5 * (R + R.T)
+
+
+class UniformDelayPrior:
+    """Uniform(0, upper) over the delay, with the log-density vector getprobabilities takes as its second argument."""
+
+    def __init__(self, upper):
+        self.lower, self.upper = 0.0, float(upper)
+
+    def logpdf(self, delays):
+        d = np.asarray(delays, dtype=np.float64)
+        return np.where((d >= self.lower) & (d <= self.upper), -np.log(self.upper - self.lower), -np.inf)
+
+
+def uniformpriordelay(*, L, z):
+    """src/uniformpriordelay.jl:10-16: Uniform(0, 10^1.559 (L 1e-44)^0.549 (1+z)); L luminosity, z redshift."""
+    return UniformDelayPrior(10.0 ** 1.559 * (L * 1e-44) ** 0.549 * (1.0 + z))
+
+
 def logrange(a, b, n):
     return np.exp(np.linspace(np.log(a), np.log(b), n))
 
@@ -123,10 +151,10 @@ class Predictor:
             yv = np.concatenate([np.asarray(a, dtype=np.float64) for a in ytest])
             try:
                 return mvnormal_logpdf(mu, Sig, yv, device=self.obj.device)
-            except PosDefException as e:
-                # the reference retries with MiscUtil.nearestposdef(Sigma; minimumeigenvalue = 1e-6) (:327-341);
-                # MiscUtil's source is not available, so the fallback is not restated here
-                raise PosDefException(e.info) from None
+            except PosDefException:
+                # :327-341 -- retry once on nearestposdef(Sigma; minimumeigenvalue = 1e-6); a second
+                # PosDefException propagates, as in the reference
+                return mvnormal_logpdf(mu, nearestposdef(Sig, minimumeigenvalue=1e-6), yv, device=self.obj.device)
         if joint:
             return self.obj.predict(self.delays, self.alpha, self.rho, [np.asarray(a, dtype=np.float64) for a in ttest])
         tt = np.asarray(ttest, dtype=np.float64).ravel()

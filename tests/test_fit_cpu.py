@@ -25,6 +25,26 @@ def test_transforms_roundtrip():
     assert np.allclose(fit.logrange(0.101, 19.999, 4)[[0, -1]], [0.101, 19.999])
 
 
+def test_uniformpriordelay():
+    pr = fit.uniformpriordelay(L=1e44, z=0.0)
+    assert abs(pr.upper - 10.0 ** 1.559) < 1e-12                     # L = 1e44, z = 0: the bare constant
+    pr = fit.uniformpriordelay(L=6e43, z=0.0258)
+    lp = pr.logpdf([-1.0, 0.0, 5.0, pr.upper, pr.upper + 1e-9])
+    assert np.isneginf(lp[[0, 4]]).all() and np.allclose(lp[1:4], -np.log(pr.upper))
+
+
+def test_nearestposdef_properties():
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((12, 12))
+    S = A + A.T                                         # indefinite
+    P = fit.nearestposdef(S, minimumeigenvalue=1e-6)
+    assert np.array_equal(P, P.T) and np.linalg.eigvalsh(P).min() >= 1e-6 * (1 - 1e-6)
+    w, V = np.linalg.eigh(S)
+    assert np.allclose(V.T @ P @ V, np.diag(np.maximum(w, 1e-6)), atol=1e-10)    # same eigenvectors, lifted spectrum
+    G = A @ A.T + np.eye(12)                            # already positive definite: unchanged
+    assert np.allclose(fit.nearestposdef(G), G, rtol=0, atol=1e-11)
+
+
 def test_gpcc_grid_lockstep_equals_single_delay_runs(oracle):
     t, y, s, _ = synthetic.simulate_lightcurves([40, 30], seed=5, span=20.0)
     cand = np.stack([np.zeros(4), np.array([0.5, 2.0, 3.5, 9.0])], 1)

@@ -344,6 +344,42 @@ def test_gpcc_end_to_end_small(gp, oracle):
     assert abs(got - refll) <= 1e-9 * abs(refll)
 
 
+def test_predict_loglik_nearestposdef_fallback(gp):
+    """marginaliseb.jl:327-341: a PosDefException in the test log-likelihood is retried once on
+    nearestposdef(Sigma_pred; minimumeigenvalue = 1e-6).  The joint prediction is stubbed with an indefinite
+    covariance so that the first device Cholesky fails."""
+    from gpcc_amd import fit
+    rng = np.random.default_rng(11)
+    n = 40
+    A = rng.standard_normal((n, n))
+    Sig = A @ A.T
+    w, V = np.linalg.eigh(Sig)
+    w[:3] = [-0.5, -1e-3, 0.0]
+    Sig = (V * w) @ V.T
+    Sig = 0.5 * (Sig + Sig.T)
+    mu = rng.standard_normal(n)
+
+    class Stub:
+        L, device = 2, 0
+
+        def predict(self, delays, alpha, rho, ttest):
+            return mu.copy(), Sig.copy()
+
+    pred = fit.Predictor(Stub(), [0.0, 1.0], [1.0, 1.0], 2.0)
+    tt = [np.arange(n // 2, dtype=float)] * 2
+    yt = [rng.standard_normal(n // 2)] * 2
+    st = [np.zeros(n // 2)] * 2
+    with pytest.raises(gp.PosDefException):
+        gp.mvnormal_logpdf(mu, Sig, np.concatenate(yt))
+    got = pred(tt, yt, st)
+    P = fit.nearestposdef(Sig, minimumeigenvalue=1e-6)
+    r = np.concatenate(yt) - mu
+    Lc = np.linalg.cholesky(P)
+    z = np.linalg.solve(Lc, r)
+    ref = -0.5 * (n * np.log(2 * np.pi) + 2 * np.sum(np.log(np.diag(Lc)))) - 0.5 * z @ z
+    assert abs(got - ref) <= 1e-6 * abs(ref)       # the lifted 1e-6 eigenvalues amplify rounding (cond ~ 1e8)
+
+
 def test_gpcc_grid_device_matches_oracle_injected(gp, oracle):
     """The lock-step fit over a small delay grid with the device objective vs the same host logic over the
     oracle: optimised log-likelihoods agree (trajectories may differ in the last bits of the objective)."""
