@@ -17,6 +17,9 @@ PRECISION_IDS = {"fp64": 0, "fp32": 1}
 PROF_NAMES = ("assemble", "panel_update", "diag_factor", "panel_trsm")
 
 # every symbol include/gpcc_hip.h declares: name -> (restype, argtypes)
+BATCH_OBJECTIVE = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.POINTER(ctypes.c_long),
+                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double))
+
 SIGNATURES = {
     "gpcc_version": (ctypes.c_int, []),
     "gpcc_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
@@ -41,6 +44,16 @@ SIGNATURES = {
                                             ctypes.c_int]),
     "gpcc_covariance": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, ctypes.c_double, c_int_p,
                                        c_double_p, c_int_p, c_double_p, c_double_p, ctypes.c_int]),
+    "gpcc_grid_loglik": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_double, ctypes.c_double, ctypes.c_ulonglong, c_double_p, c_double_p,
+                                        c_double_p, c_double_p, c_int_p, c_int_p, ctypes.POINTER(ctypes.c_longlong)]),
+    "gpcc_initial_params": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                           ctypes.c_ulonglong, c_double_p]),
+    "gpcc_neldermead_batch": (ctypes.c_int, [ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p,
+                                             BATCH_OBJECTIVE, ctypes.c_void_p, c_double_p, c_double_p, c_int_p,
+                                             ctypes.POINTER(ctypes.c_longlong)]),
+    "gpcc_unpack_params": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_double, ctypes.c_double,
+                                          c_double_p, c_double_p]),
     "gpcc_probabilities": (ctypes.c_int, [ctypes.c_int, c_double_p, c_double_p, c_double_p, ctypes.c_int]),
     "gpcc_probabilities_device": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                  ctypes.c_void_p]),

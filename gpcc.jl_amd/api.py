@@ -300,6 +300,37 @@ class Objective:
             raise PosDefException(info.value)
         return mu, Sig.T
 
+    # -- the per-delay fit over a grid (gpcc_grid_loglik) ---------------------------------------------
+    def grid_loglik(self, candidatedelays, iterations, numberofrestarts=1, initialrandom=5, rhomin=0.1, rhomax=20.0,
+                    seed=1, init_params=None):
+        """Optimised log-likelihood per row of candidatedelays (G, L): README.md:172-174 as one native call.
+        Returns (loglikel[G], alpha[G, L], rho[G], info[G], iterations[G], (f_calls, rounds))."""
+        cand = np.ascontiguousarray(np.atleast_2d(candidatedelays), dtype=np.float64)
+        G = cand.shape[0]
+        if cand.shape[1] != self.L:
+            raise ValueError("candidatedelays must be (G, %d)" % self.L)
+        if init_params is not None:
+            init_params = _d(init_params)
+            if init_params.size != numberofrestarts * initialrandom * (self.L + 1):
+                raise ValueError("init_params must be (numberofrestarts, initialrandom, L + 1)")
+        ll = np.empty(G, dtype=np.float64)
+        alpha = np.empty((G, self.L), dtype=np.float64)
+        rho = np.empty(G, dtype=np.float64)
+        info = np.empty(G, dtype=np.int32)
+        its = np.empty(G, dtype=np.int32)
+        stats = (ctypes.c_longlong * 2)()
+        self._chk(_capi.load().gpcc_grid_loglik(self._h, G, _dp(cand), int(iterations), int(numberofrestarts),
+                                                int(initialrandom), float(rhomin), float(rhomax), int(seed),
+                                                _dp(init_params) if init_params is not None else None, _dp(ll),
+                                                _dp(alpha), _dp(rho), _ip(info), _ip(its), stats))
+        return ll, alpha, rho, info, its, (int(stats[0]), int(stats[1]))
+
+    def initial_params(self, numberofrestarts=1, initialrandom=5, rhomin=0.1, rhomax=20.0, seed=1):
+        out = np.empty((numberofrestarts, initialrandom, self.L + 1), dtype=np.float64)
+        self._chk(_capi.load().gpcc_initial_params(self._h, int(numberofrestarts), int(initialrandom), float(rhomin),
+                                                   float(rhomax), int(seed), _dp(out)))
+        return out
+
     # -- profiling (bench.py) ------------------------------------------------------------------------
     def profile(self, on):
         self._chk(_capi.load().gpcc_profile_enable(self._h, int(bool(on))))
@@ -315,6 +346,16 @@ class Objective:
             self._chk(_capi.load().gpcc_profile_get(self._h, i, ctypes.byref(n), ctypes.byref(ms)))
             out[name] = (n.value, ms.value)
         return out
+
+
+def unpack_params(X, L, rhomin, rhomax):
+    """`unpack` of marginaliseb.jl:112-126 through the library (host arithmetic, no device needed)."""
+    X = np.ascontiguousarray(np.atleast_2d(X), dtype=np.float64)
+    M = X.shape[0]
+    alpha = np.empty((M, L), dtype=np.float64)
+    rho = np.empty(M, dtype=np.float64)
+    _capi.check(_capi.load().gpcc_unpack_params(M, int(L), _dp(X), float(rhomin), float(rhomax), _dp(alpha), _dp(rho)))
+    return alpha, rho
 
 
 def selftest(device=0, rate=True):

@@ -1,6 +1,7 @@
 // gpcc_hip.hip -- host side of libgpcc_hip.so: the C ABI of include/gpcc_hip.h over the gfx950
 // kernels of gpcc_kernels.hip.h.  No CPU fallback: every compute entry needs a HIP device.
 #include "gpcc_kernels.hip.h"
+#include "gpcc_fit.h"
 
 #include "../../include/gpcc_hip.h"
 
@@ -803,6 +804,156 @@ extern "C" int gpcc_probabilities(int G, const double *loglik, const double *log
     }
     hipFree(d);
     if (e != hipSuccess) return fail(nullptr, GPCC_ERR_HIP, "gpcc_probabilities: %s", hipGetErrorString(e));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// gpcc_grid_loglik: the optimised per-delay log-likelihood (host logic in gpcc_fit.h, objective = gpcc_loglik_batch)
+extern "C" int gpcc_unpack_params(int M, int L, const double *X, double rhomin, double rhomax, double *alpha, double *rho)
+{
+    if (M < 0 || L < 1 || L > GPCC_MAXL) return fail(nullptr, GPCC_ERR_ARGUMENT, "bad M=%d or L=%d", M, L);
+    if (M == 0) return 0;
+    if (!X || !alpha || !rho) return fail(nullptr, GPCC_ERR_ARGUMENT, "NULL pointer");
+    for (long i = 0; i < M; ++i) {
+        const double *x = X + i * (L + 1);
+        for (int l = 0; l < L; ++l) alpha[i * L + l] = gpccfit::makepositive(x[l]) + 1e-8;    // makeα, marginaliseb.jl:112
+        rho[i] = gpccfit::transformbetween(x[L], rhomin, rhomax);                             // makeρ, :114
+    }
+    return 0;
+}
+
+static void band_variances(gpcc_handle_t h, double *vary)
+{
+    long off = 0;
+    for (int l = 0; l < h->L; ++l) {
+        const int n = h->Nl[l];
+        double m = 0.0, v = 0.0;
+        for (int i = 0; i < n; ++i) m += h->y_host[off + i];
+        m /= n;
+        for (int i = 0; i < n; ++i) v += (h->y_host[off + i] - m) * (h->y_host[off + i] - m);
+        vary[l] = n > 1 ? v / (n - 1) : 0.0;
+        off += n;
+    }
+}
+
+extern "C" int gpcc_initial_params(gpcc_handle_t h, int numberofrestarts, int initialrandom, double rhomin, double rhomax,
+                                   unsigned long long seed, double *out)
+{
+    if (!h) return fail(h, GPCC_ERR_ARGUMENT, "NULL handle");
+    if (numberofrestarts < 1 || initialrandom < 1 || !(rhomin > 0.0) || !(rhomax > rhomin + 2e-3) || !out)
+        return fail(h, GPCC_ERR_ARGUMENT, "bad fit options (restarts %d, initialrandom %d, rho in (%g, %g))",
+                    numberofrestarts, initialrandom, rhomin, rhomax);
+    double vary[GPCC_MAXL];
+    band_variances(h, vary);
+    gpccfit::initial_params(h->L, numberofrestarts, initialrandom, rhomin, rhomax, seed, vary, out);
+    return 0;
+}
+
+extern "C" int gpcc_neldermead_batch(long P, int n, int iterations, double g_tol, const double *x0,
+                                     gpcc_batch_objective_t f, void *ctx, double *xmin, double *fmin,
+                                     int *iterations_out, long long *stats_out)
+{
+    if (P < 0 || n < 1 || iterations < 0) return fail(nullptr, GPCC_ERR_ARGUMENT, "bad P=%ld, n=%d or iterations=%d", P, n, iterations);
+    if (P == 0) return 0;
+    if (!x0 || !f || !xmin || !fmin) return fail(nullptr, GPCC_ERR_ARGUMENT, "NULL pointer");
+    gpccfit::BatchedNelderMead nm(P, n, iterations, g_tol);
+    const int rc = nm.run(f, ctx, x0, xmin, fmin);
+    if (rc) return rc;
+    if (iterations_out)
+        for (long p = 0; p < P; ++p) iterations_out[p] = nm.it[p];
+    if (stats_out) {
+        stats_out[0] = nm.f_calls;
+        stats_out[1] = nm.rounds;
+    }
+    return 0;
+}
+
+namespace {
+struct FitEval {
+    gpcc_handle_t h;
+    const double *cand;   // G x L
+    int R, L;
+    double rhomin, rhomax;
+    std::vector<double> delays, alpha, rho, ll;
+    std::vector<int> info;
+};
+
+int fit_eval(void *vctx, long K, const long *pidx, const double *X, double *f)
+{
+    FitEval &e = *static_cast<FitEval *>(vctx);
+    const int L = e.L;
+    if (K > 0x7fffffffL) return fail(e.h, GPCC_ERR_ARGUMENT, "optimiser round of %ld evaluations", K);
+    e.delays.resize(K * L); e.alpha.resize(K * L); e.rho.resize(K); e.ll.resize(K); e.info.resize(K);
+    for (long i = 0; i < K; ++i)
+        for (int l = 0; l < L; ++l) e.delays[i * L + l] = e.cand[(pidx[i] / e.R) * L + l];
+    int rc = gpcc_unpack_params((int)K, L, X, e.rhomin, e.rhomax, e.alpha.data(), e.rho.data());
+    if (rc) return rc;
+    rc = gpcc_loglik_batch(e.h, (int)K, e.delays.data(), e.alpha.data(), e.rho.data(), e.ll.data(), e.info.data());
+    if (rc) return rc;
+    for (long i = 0; i < K; ++i)   // safewrapper(negativeobjective), :149-153: a failed evaluation is +Inf
+        f[i] = e.info[i] == 0 ? -e.ll[i] : std::numeric_limits<double>::infinity();
+    return 0;
+}
+}   // namespace
+
+extern "C" int gpcc_grid_loglik(gpcc_handle_t h, int G, const double *delays, int iterations, int numberofrestarts,
+                                int initialrandom, double rhomin, double rhomax, unsigned long long seed,
+                                const double *init_params, double *loglik_out, double *alpha_out, double *rho_out,
+                                int *info_out, int *iterations_out, long long *stats_out)
+{
+    if (!h) return fail(h, GPCC_ERR_ARGUMENT, "NULL handle");
+    if (G < 0) return fail(h, GPCC_ERR_ARGUMENT, "G=%d < 0", G);
+    if (G == 0) return 0;
+    if (!delays || !loglik_out || !alpha_out || !rho_out || !info_out) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
+    const int L = h->L, R = numberofrestarts, C = initialrandom, n = L + 1;
+    if (R < 1 || C < 1 || iterations < 0 || !(rhomin > 0.0) || !(rhomax > rhomin + 2e-3))
+        return fail(h, GPCC_ERR_ARGUMENT, "bad fit options (iterations %d, restarts %d, initialrandom %d, rho in (%g, %g))",
+                    iterations, R, C, rhomin, rhomax);
+    const long P = (long)G * R;
+    if (P * (long)std::max(C, n + 1) > 0x7fffffffL) return fail(h, GPCC_ERR_ARGUMENT, "G x restarts = %ld is too large", P);
+    std::vector<double> cands((size_t)R * C * n);
+    if (init_params) memcpy(cands.data(), init_params, sizeof(double) * cands.size());
+    else {
+        double vary[GPCC_MAXL];
+        band_variances(h, vary);
+        gpccfit::initial_params(L, R, C, rhomin, rhomax, seed, vary, cands.data());
+    }
+    FitEval ev{h, delays, R, L, rhomin, rhomax, {}, {}, {}, {}, {}};
+
+    // the best of the random candidates starts each problem (:209); problem p = (delay p / R, restart p % R) and
+    // every delay sees the same candidates (each reference gpcc call seeds its own generator with `seed`)
+    std::vector<long> pid((size_t)P * C);
+    std::vector<double> X((size_t)P * C * n), f0((size_t)P * C), x0((size_t)P * n);
+    for (long p = 0; p < P; ++p)
+        for (int c = 0; c < C; ++c) {
+            pid[p * C + c] = p;
+            memcpy(&X[(p * C + c) * n], &cands[((size_t)(p % R) * C + c) * n], sizeof(double) * n);
+        }
+    int rc = fit_eval(&ev, P * C, pid.data(), X.data(), f0.data());
+    if (rc) return rc;
+    for (long p = 0; p < P; ++p) {
+        int best = 0;
+        for (int c = 1; c < C; ++c)
+            if (f0[p * C + c] < f0[p * C + best]) best = c;
+        memcpy(&x0[p * n], &X[(p * C + best) * n], sizeof(double) * n);
+    }
+    gpccfit::BatchedNelderMead nm(P, n, iterations, 1e-6);            // Optim.Options(iterations, g_tol = 1e-6), :205
+    std::vector<double> xmin((size_t)P * n), fmin(P);
+    rc = nm.run(fit_eval, &ev, x0.data(), xmin.data(), fmin.data());
+    if (rc) return rc;
+    for (int g = 0; g < G; ++g) {
+        long pick = (long)g * R;                                     // best restart, :224
+        for (int r = 1; r < R; ++r)
+            if (fmin[(long)g * R + r] < fmin[pick]) pick = (long)g * R + r;
+        loglik_out[g] = -fmin[pick];                                 // :351
+        gpcc_unpack_params(1, L, &xmin[pick * n], rhomin, rhomax, alpha_out + (long)g * L, rho_out + g);
+        info_out[g] = std::isfinite(fmin[pick]) ? 0 : 1;             // 1: no candidate and no simplex vertex was valid
+        if (iterations_out) iterations_out[g] = nm.it[pick];
+    }
+    if (stats_out) {
+        stats_out[0] = nm.f_calls + P * C;
+        stats_out[1] = nm.rounds + 1;
+    }
     return 0;
 }
 

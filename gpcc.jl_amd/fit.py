@@ -81,9 +81,15 @@ class GridFit:
 
 
 def gpcc_grid(tarray, yarray, stdarray, *, kernel, candidatedelays, iterations, seed=1, numberofrestarts=1,
-              initialrandom=5, rhomin=0.1, rhomax=20.0, objective=None, device=0, marginalise_b=True):
+              initialrandom=5, rhomin=0.1, rhomax=20.0, objective=None, device=0, marginalise_b=True, engine=None,
+              unpack=None):
     """Fits the GPCC model for each row of candidatedelays (G, L): the README's
-    `map(delay -> gpcc(...; delays = [0; delay])[1], candidatedelays)` as one lock-step batch."""
+    `map(delay -> gpcc(...; delays = [0; delay])[1], candidatedelays)` as one lock-step batch.
+
+    engine "native" (default with a device Objective): the whole fit is one gpcc_grid_loglik call, the random
+    candidates drawn here (numpy) and handed over as init_params.  engine "python" (default when another
+    objective is injected): the same algorithm in numpy (neldermead.py) over objective.loglik_batch; `unpack`
+    may replace the numpy parameter transforms (api.unpack_params = the library's own)."""
     cand = np.ascontiguousarray(np.atleast_2d(candidatedelays), dtype=np.float64)
     G, L = cand.shape
     assert L == len(tarray) == len(yarray) == len(stdarray)          # marginaliseb.jl:78
@@ -105,10 +111,20 @@ def gpcc_grid(tarray, yarray, stdarray, *, kernel, candidatedelays, iterations, 
                 cands[i, c, :L] = invmakepositive(vary * (rg.random(L) * (1.2 - 0.8) + 0.8))   # sampleα, :188
                 cands[i, c, L] = invtransformbetween(rho0[i], rhomin, rhomax)
         P = G * R                                                        # problem p = (delay p // R, restart p % R)
+        if engine is None:
+            engine = "native" if isinstance(obj, Objective) else "python"
+        if engine == "native":
+            ll, alpha, rho, info, its, (f_calls, rounds) = obj.grid_loglik(
+                cand, iterations, numberofrestarts=R, initialrandom=initialrandom, rhomin=rhomin, rhomax=rhomax,
+                seed=seed, init_params=cands)
+            return GridFit(ll, alpha, rho, f_calls, rounds, its.astype(np.int64))
 
         def negobj(pidx, X):
-            alpha = makepositive(X[:, :L]) + 1e-8                        # makeα, :112
-            rho = transformbetween(X[:, L], rhomin, rhomax)              # makeρ, :114
+            if unpack is not None:
+                alpha, rho = unpack(X, L, rhomin, rhomax)
+            else:
+                alpha = makepositive(X[:, :L]) + 1e-8                    # makeα, :112
+                rho = transformbetween(X[:, L], rhomin, rhomax)          # makeρ, :114
             ll, info = obj.loglik_batch(cand[pidx // R], alpha, rho)
             return np.where(info == 0, -ll, np.inf)                      # safewrapper(negativeobjective), :149-153
 
@@ -123,8 +139,9 @@ def gpcc_grid(tarray, yarray, stdarray, *, kernel, candidatedelays, iterations, 
         fmin = fmin.reshape(G, R)
         pick = np.argmin(fmin, axis=1)                                   # best restart, :224
         xsel = xmin.reshape(G, R, L + 1)[np.arange(G), pick]
-        return GridFit(-fmin[np.arange(G), pick], makepositive(xsel[:, :L]) + 1e-8,
-                       transformbetween(xsel[:, L], rhomin, rhomax), nm.f_calls + P * initialrandom, nm.rounds + 1,
+        a_sel, r_sel = (unpack(xsel, L, rhomin, rhomax) if unpack is not None else
+                        (makepositive(xsel[:, :L]) + 1e-8, transformbetween(xsel[:, L], rhomin, rhomax)))
+        return GridFit(-fmin[np.arange(G), pick], a_sel, r_sel, nm.f_calls + P * initialrandom, nm.rounds + 1,
                        nm.iterations_done.reshape(G, R)[np.arange(G), pick])
     finally:
         if own:

@@ -122,6 +122,44 @@ int gpcc_covariance(int kernel_id, int L, const double *scale, const double *del
                     const int *Nx, const double *x, const int *Ny, const double *y, double *out,
                     int device_id);
 
+/* The per-delay model FIT for a whole grid of candidate delays -- what README.md:172-174 maps over
+ * (`gpcc(...; delays = [0; d])[1]` for each d) -- as one call.  For each row of delays (G x L) and each
+ * restart: the best of `initialrandom` random candidates (marginaliseb.jl:209) starts Nelder-Mead with
+ * Optim's defaults and Options(iterations, g_tol = 1e-6) (:205-211) over the unconstrained parameters of
+ * `unpack` (:112-126); the best restart wins (:222-226).  All G x numberofrestarts minimisations advance in
+ * lock-step, every optimiser round being one gpcc_loglik_batch; each keeps its own trajectory.
+ *   loglik_out[g] = -result.minimum (:351), alpha_out (G x L), rho_out[g] = the optimised hyper-parameters,
+ *   info_out[g]   = 0, or 1 when no evaluated point was valid (loglik_out[g] = -Inf),
+ *   iterations_out[g] (may be NULL) = Nelder-Mead iterations of the winning restart,
+ *   stats_out (may be NULL) = {objective evaluations, batched rounds}.
+ * init_params: numberofrestarts x initialrandom x (L+1) candidates in the optimiser's unconstrained
+ * coordinates (the same for every delay: each reference gpcc call seeds its own generator with `seed`).  A
+ * Julia caller draws them exactly as the reference does (MersenneTwister(seed), :160-196) and passes them;
+ * NULL = drawn here with the same recipe from xoshiro256++(seed) (gpcc_initial_params shows them). */
+int gpcc_grid_loglik(gpcc_handle_t h, int G, const double *delays, int iterations, int numberofrestarts,
+                     int initialrandom, double rhomin, double rhomax, unsigned long long seed,
+                     const double *init_params, double *loglik_out, double *alpha_out, double *rho_out,
+                     int *info_out, int *iterations_out, long long *stats_out);
+
+/* The candidates gpcc_grid_loglik uses when init_params == NULL (out: restarts x initialrandom x (L+1)). */
+int gpcc_initial_params(gpcc_handle_t h, int numberofrestarts, int initialrandom, double rhomin, double rhomax,
+                        unsigned long long seed, double *out);
+
+/* The optimiser inside gpcc_grid_loglik on its own: P independent Nelder-Mead minimisations of dimension n in
+ * lock-step (Optim.jl's NelderMead defaults as the reference uses them, marginaliseb.jl:205-211) over a batched
+ * objective.  f(ctx, K, pidx, X, out) must write out[i] = objective of problem pidx[i] at row i of X (K x n);
+ * NaN / +Inf = rejected point; non-zero return aborts with that code.  x0, xmin: P x n; fmin: P;
+ * iterations_out (P) and stats_out ({evaluations, rounds}) may be NULL.  Host only; the tests pin this against the
+ * numpy and the scalar restatements of the same algorithm. */
+typedef int (*gpcc_batch_objective_t)(void *ctx, long K, const long *pidx, const double *X, double *out);
+int gpcc_neldermead_batch(long P, int n, int iterations, double g_tol, const double *x0, gpcc_batch_objective_t f,
+                          void *ctx, double *xmin, double *fmin, int *iterations_out, long long *stats_out);
+
+/* `unpack` of marginaliseb.jl:112-126 for M parameter vectors X (M x (L+1)): alpha = makepositive(x[1:L]) + 1e-8,
+ * rho = transformbetween(x[L+1], rhomin, rhomax).  MiscUtil.jl's source is not part of the reference tree:
+ * makepositive is taken to be softplus, transformbetween(x, a, b) = a + (b - a) / (1 + exp(-x)).  Host only. */
+int gpcc_unpack_params(int M, int L, const double *X, double rhomin, double rhomax, double *alpha, double *rho);
+
 /* getprobabilities(loglikel[, logpriorpdfvalues]) of src/getprobabilities.jl:1-20;
  * logprior == NULL is the 1-argument form (log-prior of ones, :3). */
 int gpcc_probabilities(int G, const double *loglik, const double *logprior, double *out,

@@ -399,6 +399,42 @@ def test_gpcc_grid_device_matches_oracle_injected(gp, oracle):
     assert abs(grid[np.argmax(p)] - 2.0) <= 1.0
 
 
+def test_native_grid_fit_equals_python_host_logic(gp, oracle):
+    """gpcc_grid_loglik (C++ lock-step Nelder-Mead inside the library) vs the numpy host logic driving the same
+    device objective with the library's own `unpack`: identical requests, hence identical bits; the returned value
+    is the objective at the returned hyper-parameters (checked against the oracle); restarts; 3 bands; the
+    NULL-init_params recipe equals passing gpcc_initial_params' output."""
+    from gpcc_amd import api, fit, synthetic
+    for Nl, kern, R, iters in (([60, 50], "matern32", 1, 40), ([45, 40, 35], "OU", 3, 25)):
+        L = len(Nl)
+        t, y, s, _ = synthetic.simulate_lightcurves(Nl, seed=2, span=20.0)
+        rng = np.random.default_rng(5)
+        cand = np.concatenate([np.zeros((9, 1)), rng.uniform(0.0, 8.0, (9, L - 1))], axis=1)
+        with gp.Objective(t, y, s, kern) as obj:
+            nat = fit.gpcc_grid(t, y, s, kernel=kern, candidatedelays=cand, iterations=iters, numberofrestarts=R,
+                                rhomax=30.0, objective=obj, engine="native")
+            py = fit.gpcc_grid(t, y, s, kernel=kern, candidatedelays=cand, iterations=iters, numberofrestarts=R,
+                               rhomax=30.0, objective=obj, engine="python", unpack=api.unpack_params)
+            assert np.array_equal(nat.loglikel, py.loglikel)
+            assert np.array_equal(nat.alpha, py.alpha) and np.array_equal(nat.rho, py.rho)
+            assert np.array_equal(nat.iterations_done, py.iterations_done)
+            assert (nat.f_calls, nat.rounds) == (py.f_calls, py.rounds)
+            ref, rinfo = oracle.loglik_batch(kern, t, y, s, cand, nat.alpha, nat.rho, True, nthreads=8)
+            assert (rinfo == 0).all() and np.max(np.abs(nat.loglikel - ref) / np.abs(ref)) <= 1e-8
+            # the library's own random candidates: NULL == explicit
+            init = obj.initial_params(numberofrestarts=R, initialrandom=4, rhomin=0.1, rhomax=30.0, seed=7)
+            assert init.shape == (R, 4, L + 1) and np.all(np.isfinite(init))
+            a = obj.grid_loglik(cand, iters, numberofrestarts=R, initialrandom=4, rhomin=0.1, rhomax=30.0, seed=7)
+            b = obj.grid_loglik(cand, iters, numberofrestarts=R, initialrandom=4, rhomin=0.1, rhomax=30.0, seed=123,
+                                init_params=init)
+            assert all(np.array_equal(u, v) for u, v in zip(a[:5], b[:5])) and a[5] == b[5]
+            assert (a[3] == 0).all() and np.all(a[0] > ref - 50.0)
+            c = obj.grid_loglik(cand, iters, numberofrestarts=R, initialrandom=4, rhomin=0.1, rhomax=30.0, seed=8)
+            assert not np.array_equal(a[0], c[0])                       # the seed matters
+            with pytest.raises(gp.GpccError):
+                obj.grid_loglik(cand, iters, rhomin=5.0, rhomax=5.0)
+
+
 # ---- fp32 path: K0 = delayedCovariance + Sobs factorised in fp32 (fp64 diagonal blocks and right-hand sides),
 # ---- the offset prior B = Q Sigma_b Q' through the L x L capacitance matrix in fp64.  Bar: 1e-3 relative.
 FP32_RTOL = 1e-3

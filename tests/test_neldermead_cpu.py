@@ -112,3 +112,83 @@ def test_rejected_points_behave_like_safewrapper():
     nm = BatchedNelderMead(x0, lambda pid, X: np.array([f(x) if np.isfinite(f(x)) else np.nan for x in X]), 500)
     xb, fb = nm.run()
     assert np.all(fb < 1e-5) and np.allclose(xb, [0.2, -0.1], atol=5e-3)
+
+
+def native_nm(fun, x0, iterations, g_tol=1e-6):
+    """gpcc_neldermead_batch (the C++ optimiser inside gpcc_grid_loglik) over a Python objective."""
+    import ctypes
+
+    from gpcc_amd import _capi
+    lib = _capi.load()
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    P, n = x0.shape
+    seen = []
+
+    def cb(ctx, K, pidx, X, out):
+        Xa = np.ctypeslib.as_array(X, shape=(K, n))
+        pa = np.ctypeslib.as_array(pidx, shape=(K,))
+        seen.append(pa.copy())
+        vals = fun(pa, Xa)
+        for i in range(K):
+            out[i] = vals[i]
+        return 0
+
+    cfun = _capi.BATCH_OBJECTIVE(cb)
+    xmin, fmin = np.empty((P, n)), np.empty(P)
+    its = np.empty(P, dtype=np.int32)
+    stats = (ctypes.c_longlong * 2)()
+    dp = ctypes.POINTER(ctypes.c_double)
+    rc = lib.gpcc_neldermead_batch(P, n, iterations, g_tol, x0.ctypes.data_as(dp), cfun, None, xmin.ctypes.data_as(dp),
+                                   fmin.ctypes.data_as(dp), its.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), stats)
+    assert rc == 0, _capi.last_error()
+    return xmin, fmin, its, (stats[0], stats[1]), seen
+
+
+def test_native_optimiser_equals_numpy_optimiser_bitwise():
+    """Same requests in the same order, same decisions, same bits: the C++ lock-step Nelder-Mead of
+    gpcc_grid_loglik vs neldermead.BatchedNelderMead (and through it the scalar Optim restatement above)."""
+    rng = np.random.default_rng(4)
+    for fun, n in ((rosen, 2), (himmel, 2), (bowl3, 3)):
+        x0 = rng.standard_normal((23, n)) * 2
+        fb = lambda pid, X: np.array([fun(x) for x in X])          # noqa: E731
+        for iters in (0, 1, 9, 75, 3000):
+            seen_py = []
+
+            def fpy(pid, X):
+                seen_py.append(np.array(pid))
+                return fb(pid, X)
+
+            nm = BatchedNelderMead(x0, fpy, iterations=iters, g_tol=1e-6)
+            xp, fp = nm.run()
+            xn, fn, its, (calls, rounds), seen = native_nm(fb, x0, iters)
+            assert np.array_equal(xn, xp) and np.array_equal(fn, fp)
+            assert np.array_equal(its, nm.iterations_done) and calls == nm.f_calls and rounds == nm.rounds
+            assert len(seen) == len(seen_py) and all(np.array_equal(a, b) for a, b in zip(seen, seen_py))
+
+
+def test_native_optimiser_rejected_points_and_errors():
+    def f(pid, X):
+        return np.array([np.nan if x[0] < -0.5 else (x[0] - 0.2) ** 2 + (x[1] + 0.1) ** 2 for x in X])
+
+    x0 = np.array([[1.0, 1.0], [0.0, 2.0], [3.0, -3.0]])
+    nm = BatchedNelderMead(x0, f, 500)
+    xp, fp = nm.run()
+    xn, fn, its, _, _ = native_nm(f, x0, 500)
+    assert np.array_equal(xn, xp) and np.array_equal(fn, fp) and np.all(fn < 1e-5)
+    # all points rejected: finishes, reports +Inf
+    xn, fn, its, _, _ = native_nm(lambda pid, X: np.full(len(X), np.inf), x0, 50)
+    assert np.all(np.isposinf(fn))
+    from gpcc_amd import _capi
+    assert _capi.load().gpcc_neldermead_batch(3, 0, 5, 1e-6, None, _capi.BATCH_OBJECTIVE(lambda *a: 0), None, None, None,
+                                              None, None) == -1
+
+
+def test_unpack_params_matches_numpy_transforms():
+    from gpcc_amd import api, fit
+    rng = np.random.default_rng(9)
+    X = np.concatenate([rng.standard_normal((50, 4)) * 8, [[40.0, -40.0, 0.0, 700.0], [31.0, 29.9, -745.0, -800.0]]])
+    alpha, rho = api.unpack_params(X, 3, 0.1, 300.0)
+    np.testing.assert_allclose(alpha, fit.makepositive(X[:, :3]) + 1e-8, rtol=1e-14)
+    with np.errstate(over="ignore"):
+        np.testing.assert_allclose(rho, fit.transformbetween(X[:, 3], 0.1, 300.0), rtol=1e-14)
+    assert np.all(alpha > 0) and np.all((rho >= 0.1) & (rho <= 300.0))
