@@ -51,3 +51,40 @@ def sharded_loglik(evaluate, delays, alpha, rho, group=None, device=None):
         out_ll[a:b] = gathered[r, 0, :b - a]
         out_info[a:b] = gathered[r, 1, :b - a].astype(np.int32)
     return out_ll, out_info
+
+
+def sharded_grid_fit(fit_block, candidatedelays, group=None, device=None):
+    """The per-delay FIT (gpcc_grid_loglik) over the GPUs of a node.  Nelder-Mead iteration counts differ a
+    little from delay to delay and neighbouring delays behave alike, so the rows of candidatedelays (G, L) are
+    dealt round-robin (rank r takes rows r, r + world, ...), fitted with no data-path
+    collective, and ONE all_gather returns [loglik | alpha | rho | info] rows to every rank.
+
+    fit_block(cand_block) -> (loglik[g], alpha[g, L], rho[g], info[g]); in the product
+    `lambda c: obj.grid_loglik(c, iterations, ...)[:4]`.  Returns (loglik[G], alpha[G, L], rho[G], info[G])."""
+    import torch
+    import torch.distributed as dist
+
+    cand = np.ascontiguousarray(np.atleast_2d(candidatedelays), dtype=np.float64)
+    G, L = cand.shape
+    if not (dist.is_available() and dist.is_initialized()):
+        ll, alpha, rho, info = fit_block(cand)
+        return np.asarray(ll), np.asarray(alpha), np.asarray(rho), np.asarray(info, dtype=np.int32)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    mine_rows = cand[rank::world]
+    g = len(mine_rows)
+    cap, K = (G + world - 1) // world, L + 3
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
+    block = np.zeros((cap, K))
+    if g:
+        ll, alpha, rho, info = fit_block(mine_rows)
+        block[:g, 0], block[:g, 1:1 + L], block[:g, 1 + L], block[:g, 2 + L] = ll, alpha, rho, info
+    mine = torch.as_tensor(block.ravel(), device=device)
+    gathered = torch.empty(world * cap * K, dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(gathered, mine, group=group)   # the single collective of the path
+    gathered = gathered.cpu().numpy().reshape(world, cap, K)
+    out = np.empty((G, K))
+    for r in range(world):
+        n_r = len(range(r, G, world))
+        out[r::world] = gathered[r, :n_r]
+    return out[:, 0].copy(), out[:, 1:1 + L].copy(), out[:, 1 + L].copy(), out[:, 2 + L].astype(np.int32)

@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 
 import torch.distributed as dist  # noqa: E402
 
-from gpcc_amd import shard_bounds, sharded_loglik, synthetic  # noqa: E402
+from gpcc_amd import fit, shard_bounds, sharded_grid_fit, sharded_loglik, synthetic  # noqa: E402
 from oracle import oracle  # noqa: E402  (tests may use the oracle)
 
 
@@ -40,6 +40,25 @@ def main():
         ok = rinfo == 0
         assert np.array_equal(ll[ok], ref[ok])
         assert np.isnan(ll[~ok]).all()
+    # the per-delay fit, dealt round-robin: every rank ends with the fit of ALL delays, equal to the unsharded fit
+    class O:
+        def loglik_batch(self, d, a, r):
+            return oracle.loglik_batch("OU", t, y, s, d, a, r, True)
+
+    for G in (7, 1):
+        cand = np.stack([np.zeros(G), np.linspace(0.5, 6.0, G)], 1)
+        seen = []
+
+        def fit_block(c):
+            seen.append(c.copy())
+            r = fit.gpcc_grid(t, y, s, kernel="OU", candidatedelays=c, iterations=6, rhomax=20.0, objective=O())
+            return r.loglikel, r.alpha, r.rho, np.zeros(len(c), dtype=np.int32)
+
+        ll, al, rh, info = sharded_grid_fit(fit_block, cand)
+        assert (len(seen) == 1 and np.array_equal(seen[0], cand[rank::world])) or (len(seen) == 0 and rank >= G)
+        full = fit.gpcc_grid(t, y, s, kernel="OU", candidatedelays=cand, iterations=6, rhomax=20.0, objective=O())
+        assert np.array_equal(ll, full.loglikel) and np.array_equal(al, full.alpha) and np.array_equal(rh, full.rho)
+        assert ll.shape == (G,) and al.shape == (G, 2) and (info == 0).all()
     dist.barrier()
     with open(os.path.join(sys.argv[1], "ok_%d" % rank), "w") as f:
         f.write("ok")
