@@ -576,10 +576,11 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_trsm(GpccCtx c, GpccGroup g
 // solve), sum log L_ii (logdet of PDMat), W_k = inv(L_kk) Z_k and the Gram matrix W^T W (sqmahal);
 // the last step writes loglik = -(N log 2pi + logdet K)/2 - (Y-bbar)' K^-1 (Y-bbar)/2
 // (Distributions.logpdf, marginaliseb.jl:139), in woodbury mode through the L x L capacitance matrix.
-//   per 16-block jb: (1) wave 0 factors the 16x16 diagonal block and inverts it in REGISTERS (lane =
-//   row resp. column, broadcasts by v_readlane);  (2) panel rows below: P = A inv(D)^T by MFMA;
-//   (3) trailing update C -= P P^T by MFMA.  Then inv(L) is assembled block-wise by MFMA: the
-//   accumulator of S = sum_m L[i][m] X[m][j] is directly the B operand of X[i][j] = -inv(D_i) S.
+//   per 16-block jb: (A) wave 0 factors the 16x16 diagonal block and inverts it in REGISTERS (lanes =
+//   rows of L and columns of the inverse, broadcasts by v_readlane);  (B) panel rows below: P = A inv(D)^T by
+//   MFMA;  (C) trailing update C -= P P^T by MFMA;  (X) row jb of inv(L) block-wise by MFMA: the accumulator
+//   of S = sum_m L[i][m] X[m][j] is directly the B operand of X[i][j] = -inv(D_i) S.  Software-pipelined:
+//   (A) of block jb+1 runs on wave 0 while waves 1-3 do (C) and (X) of block jb.
 //   X's off-diagonal blocks live transposed in the (dead) upper triangle of the LDS image.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ double gpcc_bcast(double v, int srclane)
@@ -587,6 +588,25 @@ __device__ __forceinline__ double gpcc_bcast(double v, int srclane)
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
     return __hiloint2double(hi, lo);
+}
+
+// sqrt(d) and 1/sqrt(d) from ONE v_rsq_f64 (about 2^-23 relative) by two coupled Goldschmidt steps and a final
+// residual correction of the root: both within 1-2 ulp, a third of the dependent instructions of sqrt() followed by
+// an IEEE division.  Pivots are O(sigma^2 .. alpha^2 N): no scaling for denormals; d <= 0 / NaN gives NaN (the
+// caller has flagged the pivot by then).
+__device__ __forceinline__ void gpcc_sqrt_rsqrt(double d, double &sq, double &inv)
+{
+    const double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double e = __builtin_fma(-g, g, d);
+    sq = __builtin_fma(e, h, g);
+    inv = h + h;
 }
 
 template <typename T>
@@ -601,6 +621,7 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
     double *sz = sDinv + 8 * 16 * DLD;          // nrhs x 128: Z_k, later W_k
     double *sr = sz + GPCC_MAXRHS * GPCC_TILE;  // 128 log L_ii
     double *sG = sr + GPCC_TILE;                // nrhs x nrhs Gram matrix
+    double *sld = sG + GPCC_MAXRHS * GPCC_MAXRHS;   // sum log L_ii of this block
     int *sbad = (int *)(sG + GPCC_MAXRHS * GPCC_MAXRHS + 1);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, q = lane >> 4;
@@ -617,14 +638,14 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
     }
     T *tiles = (T *)c.tiles + (long)slot * c.slot_stride;
     T *Tt = tiles + gpcc_tile_off(k, k);
-    // 16-byte pieces, 8 loads in flight per thread (one load per iteration would serialise 64 HBM round trips)
+    // 16-byte pieces, 16 loads in flight per thread (one load per iteration would serialise 64 HBM round trips)
     constexpr int NPIECE = GPCC_TILE_ELEMS / P::EP;   // pieces per tile
-    for (int p0 = tid; p0 < NPIECE; p0 += 256 * 8) {
-        typename P::v16 v[8];
+    for (int p0 = tid; p0 < NPIECE; p0 += 256 * 16) {
+        typename P::v16 v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *(const typename P::v16 *)(Tt + (long)(p0 + 256 * u) * P::EP);
+        for (int u = 0; u < 16; ++u) v[u] = *(const typename P::v16 *)(Tt + (long)(p0 + 256 * u) * P::EP);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
             const int e = (p0 + 256 * u) * P::EP;   // storage position of the piece's first element
             const int ch = e / (GPCC_TILE * P::KC), rem = e % (GPCC_TILE * P::KC), r = rem / P::KC, ks = rem % P::KC;
             const int kk = ((ks / P::EP) ^ gpcc_sw(r)) * P::EP;
@@ -636,49 +657,140 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
         sz[e] = c.z[((long)slot * nrhs + e / GPCC_TILE) * c.Np + k * GPCC_TILE + (e % GPCC_TILE)];
     if (tid == 0) *sbad = 0;
 
-    for (int jb = 0; jb < 8; ++jb) {
-        const int r0 = jb * 16;
-        __syncthreads();
+    __syncthreads();   // tile and right-hand sides are in LDS
+    // Software pipeline over the eight 16-column blocks.  Step jb: wave 0 folds column block jb-1 into the next
+    // diagonal block and factors it (A), while waves 1-3 finish the trailing update of column block jb-1 (C) and
+    // build row jb-1 of inv(L) (X); then all four waves form the panel of column block jb (B).
+    for (int jb = 0; jb <= 8; ++jb) {
+        const int r0 = jb * 16, rp = r0 - 16;   // rp: first column of the previous block
         if (wave == 0) {
-            // ---- (1) 16x16 potf2 + inverse in registers: lane l (< 16) owns row l of D
-            const int l = lr;  // lanes >= 16 shadow lanes 0..15 (in-bounds loads, results unused)
-            double a[16], invs[16];
+            if (jb > 0 && jb < 8) {   // C(jb-1) for the block the factorisation below needs: D_jb -= P_jb P_jb^T
+                d4 x;
+                double pa[4], pb[4];
 #pragma unroll
-            for (int cc = 0; cc < 16; ++cc) a[cc] = (cc <= l) ? sT[(r0 + l) * LD + r0 + cc] : 0.0;
-            int bad = 0;
+                for (int r = 0; r < 4; ++r) x[r] = sT[(r0 + q + 4 * r) * LD + r0 + lr];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const double d = gpcc_bcast(a[j], j);
-                if (!(d > 0.0) && bad == 0) bad = j + 1;  // also catches NaN
-                const double sq = sqrt(d), inv = 1.0 / sq;
-                invs[j] = inv;
-                a[j] = (l == j) ? sq : a[j] * inv;
-#pragma unroll
-                for (int cc = j + 1; cc < 16; ++cc) {
-                    const double lcj = gpcc_bcast(a[j], cc);  // L[cc][j]
-                    a[cc] = (l >= cc) ? a[cc] - a[j] * lcj : 0.0;
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    pb[s2] = sT[(r0 + lr) * LD + rp + q + 4 * s2];
+                    pa[s2] = -pb[s2];
                 }
-            }
-            // inverse: lane cx owns column cx of X = inv(L_D):  x[i] = (delta - sum_{j<i} L[i][j] x[j]) / L[i][i]
-            double xcol[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                double accv = (i == l) ? 1.0 : 0.0;
+                for (int s2 = 0; s2 < 4; ++s2) x = PD::mfma(pa[s2], pb[s2], x);
 #pragma unroll
-                for (int j = 0; j < i; ++j) accv -= gpcc_bcast(a[j], i) * xcol[j];
-                xcol[i] = accv * invs[i];
+                for (int r = 0; r < 4; ++r) sT[(r0 + q + 4 * r) * LD + r0 + lr] = x[r];
             }
-            if (lane < 16) {
+            if (jb < 8) {
+                // ---- (A) 16x16 potf2 + inverse in registers.  Lanes 0-15: lane l owns row l of D (v[cc] = A[l][cc]);
+                // lanes 16-31: lane 16 + l owns column l of X = inv(L_D) (v[cc] = delta(cc, l) - sum_j L[cc][j] X[j][l]);
+                // lanes 32-63 shadow them.  Right-looking, ONE instruction stream for both: once column j of L is
+                // final, v[j] <- v[j] / L[j][j] is L[l][j] on an L lane and X[j][l] on an X lane, and the same
+                // v[cc] -= v[j] L[cc][j] (L[cc][j] broadcast once from lane cc) updates the trailing row and the
+                // running sums.  Entries above the diagonal of D are never read back (no masking needed).
+                const bool xl = q != 0;
+                double v[16];
 #pragma unroll
                 for (int cc = 0; cc < 16; ++cc) {
-                    if (cc <= l) sT[(r0 + l) * LD + r0 + cc] = a[cc];     // L_D (lower, diagonal included)
-                    sDinv[(jb * 16 + cc) * DLD + l] = xcol[cc];            // X[cc][l] (zero above the diagonal)
+                    const double lv = sT[(r0 + lr) * LD + r0 + ((cc <= lr) ? cc : 0)];
+                    v[cc] = xl ? ((cc == lr) ? 1.0 : 0.0) : ((cc <= lr) ? lv : 0.0);
                 }
-                if (lane == 0 && bad && *sbad == 0) *sbad = r0 + bad;
+                int bad = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const double d = gpcc_bcast(v[j], j);
+                    if (!(d > 0.0) && bad == 0) bad = j + 1;  // also catches NaN
+                    double sq, inv;
+                    gpcc_sqrt_rsqrt(d, sq, inv);
+                    v[j] = (lane == j) ? sq : v[j] * inv;
+#pragma unroll
+                    for (int cc = j + 1; cc < 16; ++cc) {
+                        const double lcj = gpcc_bcast(v[j], cc);  // L[cc][j]
+                        v[cc] = __builtin_fma(-v[j], lcj, v[cc]);
+                    }
+                }
+                if (lane < 32) {
+                    double *dst = xl ? (sDinv + (jb * 16) * DLD + lr) : (sT + (r0 + lr) * LD + r0);
+                    const int st = xl ? DLD : 1;
+#pragma unroll
+                    for (int cc = 0; cc < 16; ++cc)
+                        if (xl || cc <= lr) dst[cc * st] = v[cc];   // L_D (lower) resp. X[cc][l] (zero above the diagonal)
+                    if (lane == 0 && bad && *sbad == 0) *sbad = r0 + bad;
+                }
+            }
+        } else if (jb > 0) {
+            const int w3 = wave - 1, jp = jb - 1;
+            // ---- (C) rest of the trailing update of column block jp: C[rf][cf] -= P_rf P_cf^T, jp < cf <= rf, block
+            // t = rr (rr+1)/2 + cc2 of the (7 - jp)-row triangle; t = 0 is wave 0's.  Two blocks at a time
+            // (independent MFMA chains, all LDS reads of a pair in flight together).
+            const int nb = 7 - jp, ntri = nb * (nb + 1) / 2;
+            for (int t0 = 1 + w3; t0 < ntri; t0 += 6) {
+                int rfv[2], cfv[2];
+                bool on[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int tt = t0 + 3 * u;
+                    on[u] = tt < ntri;
+                    const int te = on[u] ? tt : t0;
+                    int rr = 0;
+                    while ((rr + 1) * (rr + 2) / 2 <= te) ++rr;
+                    rfv[u] = jp + 1 + rr;
+                    cfv[u] = jp + 1 + te - rr * (rr + 1) / 2;
+                }
+                d4 x[2];
+                double pa[2][4], pb[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[u][r] = sT[(rfv[u] * 16 + q + 4 * r) * LD + cfv[u] * 16 + lr];
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) {
+                        pa[u][s2] = -sT[(rfv[u] * 16 + lr) * LD + rp + q + 4 * s2];
+                        pb[u][s2] = sT[(cfv[u] * 16 + lr) * LD + rp + q + 4 * s2];
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    x[0] = PD::mfma(pa[0][s2], pb[0][s2], x[0]);
+                    x[1] = PD::mfma(pa[1][s2], pb[1][s2], x[1]);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (on[u]) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sT[(rfv[u] * 16 + q + 4 * r) * LD + cfv[u] * 16 + lr] = x[u][r];
+                    }
+            }
+            // ---- (X) row i = jp of inv(L): X[i][j] = -inv(D_i) sum_{m = j}^{i-1} L[i][m] X[m][j], j < i (rows < i
+            // are complete); the accumulator of the sum is directly the B operand of the product with inv(D_i).
+            // Off-diagonal blocks live transposed in the (dead) upper triangle of the LDS image.
+            const int i = jp;
+            for (int j = (w3 + 30 - (ntri - 1)) % 3; j < i; j += 3) {   // continues the round-robin of (C); ntri <= 28
+                d4 S = {0.0, 0.0, 0.0, 0.0}, S1 = {0.0, 0.0, 0.0, 0.0};   // two chains: half the dependent MFMA latency
+                for (int mm = j; mm < i; ++mm) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) {
+                        const double av = sT[(i * 16 + lr) * LD + mm * 16 + q + 4 * s2];               // L[i][mm]
+                        const double bv = (mm == j) ? sDinv[(j * 16 + q + 4 * s2) * DLD + lr]          // X[j][j][k][c]
+                                                    : sT[(j * 16 + lr) * LD + mm * 16 + q + 4 * s2];   // X[mm][j]^T
+                        if (s2 & 1) S1 = PD::mfma(av, bv, S1);
+                        else S = PD::mfma(av, bv, S);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[r] += S1[r];
+                d4 Y = {0.0, 0.0, 0.0, 0.0}, Y1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {  // the accumulator S (row q+4r, col lr) IS the B operand of k-step r
+                    const double dv = -sDinv[(i * 16 + lr) * DLD + q + 4 * r];
+                    if (r & 1) Y1 = PD::mfma(dv, S[r], Y1);
+                    else Y = PD::mfma(dv, S[r], Y);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sT[(j * 16 + lr) * LD + i * 16 + q + 4 * r] = Y[r] + Y1[r];   // X[i][j] transposed
             }
         }
         __syncthreads();
-        // ---- (2) panel: P = A[rf, jb] inv(D)^T for the row fragments below, in place
+        if (jb == 8) break;
+        // ---- (B) panel of column block jb: P = A[rf, jb] inv(D_jb)^T for the row fragments below, in place
         for (int rf = jb + 1 + wave; rf < 8; rf += 4) {
             double av[4], bv[4];
 #pragma unroll
@@ -693,96 +805,67 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
             for (int r = 0; r < 4; ++r) sT[(rf * 16 + q + 4 * r) * LD + r0 + lr] = x[r];
         }
         __syncthreads();
-        // ---- (3) trailing update C[rf][cf] -= P_rf P_cf^T, jb < cf <= rf
-        int cnt = 0;
-        for (int rf = jb + 1; rf < 8; ++rf)
-            for (int cf = jb + 1; cf <= rf; ++cf, ++cnt) {
-                if ((cnt & 3) != wave) continue;
-                d4 x;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x[r] = sT[(rf * 16 + q + 4 * r) * LD + cf * 16 + lr];
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2)
-                    x = PD::mfma(-sT[(rf * 16 + lr) * LD + r0 + q + 4 * s2], sT[(cf * 16 + lr) * LD + r0 + q + 4 * s2], x);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sT[(rf * 16 + q + 4 * r) * LD + cf * 16 + lr] = x[r];
-            }
     }
-    __syncthreads();
     if (tid < GPCC_TILE) sr[tid] = log(sT[tid * LD + tid]);
-    // ---- X = inv(L) block-wise, level d = i - j (blocks of one level are independent)
-    for (int d = 1; d < 8; ++d) {
-        __syncthreads();
-        for (int j = wave; j + d < 8; j += 4) {
-            const int i = j + d;
-            d4 S = {0.0, 0.0, 0.0, 0.0};
-            for (int mm = j; mm < i; ++mm) {
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) {
-                    const double av = sT[(i * 16 + lr) * LD + mm * 16 + q + 4 * s2];               // L[i][mm]
-                    const double bv = (mm == j) ? sDinv[(j * 16 + q + 4 * s2) * DLD + lr]          // X[j][j][k][c]
-                                                : sT[(j * 16 + lr) * LD + mm * 16 + q + 4 * s2];   // X[mm][j]^T
-                    S = PD::mfma(av, bv, S);
-                }
-            }
-            d4 Y = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int r = 0; r < 4; ++r)  // the accumulator S (row q+4r, col lr) IS the B operand of k-step r
-                Y = PD::mfma(-sDinv[(i * 16 + lr) * DLD + q + 4 * r], S[r], Y);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sT[(j * 16 + lr) * LD + i * 16 + q + 4 * r] = Y[r];   // X[i][j] transposed
-        }
-    }
     __syncthreads();
-    // ---- W_k = X Z_k for every right-hand side
-    double wi[GPCC_MAXRHS];
+    // ---- W_k = X Z_k for every right-hand side, by MFMA: A = rows of X (off-diagonal blocks from the transposed
+    // image, diagonal block from sDinv), B = Z^T padded to 16 columns; wave w takes the 16-row blocks w and 7 - w
+    d4 wacc[2];
 #pragma unroll
-    for (int j = 0; j < GPCC_MAXRHS; ++j) wi[j] = 0.0;
-    if (tid < GPCC_TILE) {   // row tid of X: off-diagonal blocks from the transposed image, then its diagonal block
-        const int bi = tid >> 4, li = tid & 15;
-        for (int cb = 0; cb < bi; ++cb) {
+    for (int t2 = 0; t2 < 2; ++t2) {
+        const int bi = t2 ? 7 - wave : wave;
+        const int zrow = (lr < nrhs) ? lr : 0;
+        d4 w0 = {0.0, 0.0, 0.0, 0.0}, w1 = {0.0, 0.0, 0.0, 0.0};
+        for (int kb = 0; kb <= bi; ++kb) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {   // 16 independent LDS reads in flight
-                const int cc = cb * 16 + u;
-                const double xv = sT[cc * LD + tid];
-#pragma unroll
-                for (int j = 0; j < GPCC_MAXRHS; ++j)
-                    if (j < nrhs) wi[j] += xv * sz[j * GPCC_TILE + cc];
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const int kk = kb * 16 + q + 4 * s2;
+                const double av = (kb < bi) ? sT[kk * LD + bi * 16 + lr] : sDinv[(bi * 16 + lr) * DLD + q + 4 * s2];
+                const double zv = sz[zrow * GPCC_TILE + kk];
+                const double bv = (lr < nrhs) ? zv : 0.0;
+                if (s2 & 1) w1 = PD::mfma(av, bv, w1);
+                else w0 = PD::mfma(av, bv, w0);
             }
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const double xv = (u <= li) ? sDinv[(bi * 16 + li) * DLD + u] : 0.0;
+        for (int r = 0; r < 4; ++r) wacc[t2][r] = w0[r] + w1[r];
+    }
+    __syncthreads();   // every wave has read Z_k
+    if (lr < nrhs) {
 #pragma unroll
-            for (int j = 0; j < GPCC_MAXRHS; ++j)
-                if (j < nrhs && u <= li) wi[j] += xv * sz[j * GPCC_TILE + bi * 16 + u];
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int bi = t2 ? 7 - wave : wave;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sz[lr * GPCC_TILE + bi * 16 + q + 4 * r] = wacc[t2][r];
         }
     }
     __syncthreads();
-    if (tid < GPCC_TILE) {
+    for (int e = tid; e < nrhs * GPCC_TILE; e += 256)
+        c.w[((long)slot * nrhs + e / GPCC_TILE) * c.Np + k * GPCC_TILE + (e % GPCC_TILE)] = sz[e];
+    // Gram matrix W^T W (accumulated over the steps) and sum log L_ii: one wave per entry, fixed reduction tree
+    for (int e = wave; e < nrhs * nrhs; e += 4) {
+        const int ga = e / nrhs, gb = e % nrhs;
+        double pr = sz[ga * GPCC_TILE + lane] * sz[gb * GPCC_TILE + lane] +
+                    sz[ga * GPCC_TILE + 64 + lane] * sz[gb * GPCC_TILE + 64 + lane];
 #pragma unroll
-        for (int j = 0; j < GPCC_MAXRHS; ++j)
-            if (j < nrhs) {
-                sz[j * GPCC_TILE + tid] = wi[j];
-                c.w[((long)slot * nrhs + j) * c.Np + k * GPCC_TILE + tid] = wi[j];
-            }
+        for (int o = 32; o >= 1; o >>= 1) pr += __shfl_xor(pr, o);
+        if (lane == 0) {
+            double *gp = c.gram + (long)slot * GPCC_MAXRHS * GPCC_MAXRHS + e;
+            pr += *gp;
+            *gp = pr;
+            sG[e] = pr;
+        }
     }
-    __syncthreads();
-    if (tid < nrhs * nrhs) {  // Gram matrix, fixed summation order: deterministic
-        const int ga = tid / nrhs, gb = tid % nrhs;
-        double s = 0.0;
-        for (int i = 0; i < GPCC_TILE; ++i) s += sz[ga * GPCC_TILE + i] * sz[gb * GPCC_TILE + i];
-        double *gp = c.gram + (long)slot * GPCC_MAXRHS * GPCC_MAXRHS + tid;
-        s += *gp;
-        *gp = s;
-        sG[tid] = s;
+    if (wave == 3) {
+        double pr = sr[lane] + sr[lane + 64];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) pr += __shfl_xor(pr, o);
+        if (lane == 0) *sld = pr;
     }
     __syncthreads();
     if (c.share_p && k == c.share_p - 1) {
         // last step of the shared prefix (only the leader runs it): hand sum log L_ii and W'W over to the followers
-        double ldp = 0.0;   // same summation order as the per-evaluation path below (bitwise identical results)
-        for (int i = 0; i < GPCC_TILE; ++i) ldp += sr[i];
-        ldp += c.logdet[slot];
+        const double ldp = *sld + c.logdet[slot];   // same expression as the per-evaluation path below (bitwise identical results)
         for (int f = 1 + tid; f < g.cnt; f += 256) {
             c.logdet[g.slot0 + f] = ldp;
             for (int i = 0; i < nrhs * nrhs; ++i) c.gram[(long)(g.slot0 + f) * GPCC_MAXRHS * GPCC_MAXRHS + i] = sG[i];
@@ -790,9 +873,7 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
         __syncthreads();   // everybody has read the leader's running sum before thread 0 updates it below
     }
     if (tid == 0) {
-        double ld = 0.0;
-        for (int i = 0; i < GPCC_TILE; ++i) ld += sr[i];
-        ld += c.logdet[slot];
+        const double ld = *sld + c.logdet[slot];
         c.logdet[slot] = ld;
         int bad = *sbad;
         if (bad) c.info[slot] = k * GPCC_TILE + bad;

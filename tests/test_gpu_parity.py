@@ -662,3 +662,33 @@ def test_randomised_differential_vs_oracle(gp, oracle):
             worst = max(worst, _rel(ll[ok], ref[ok]))
     print("randomised differential test: worst relative error %.3e" % worst)
     assert worst <= LL_RTOL
+
+
+EXTREME_SHAPES = [([2, 3, 2, 5, 2, 4, 3, 2], "matern32", True), ([40, 3, 17, 64, 2, 90, 31, 128], "OU", True),
+                  ([40, 3, 17, 64, 2, 90, 31, 128], "matern52", False), ([1], "rbf", False), ([2], "rbf", True),
+                  ([127], "OU", True), ([128], "OU", True), ([129], "OU", True), ([1, 1], "OU", False),
+                  ([255, 257], "matern32", True)]
+
+
+@pytest.mark.parametrize("prec,tol", [("fp64", 1e-9), ("fp32", FP32_RTOL)])
+def test_extreme_shapes(gp, oracle, prec, tol):
+    """The maximum band count (8), one- and two-observation bands, totals on either side of a tile edge (127 / 128 /
+    129), N = 1: device == oracle; a ninth band and a one-observation band with marginalised offsets (var undefined
+    in the reference, marginaliseb.jl:91) are argument errors."""
+    rng = np.random.default_rng(0)
+    for Nl, kern, mb in EXTREME_SHAPES:
+        L, M = len(Nl), 5
+        t = [rng.uniform(0, 30, n) for n in Nl]
+        y = [rng.standard_normal(n) * 2 + 5 * l for l, n in enumerate(Nl)]
+        s = [rng.uniform(0.3, 1.0, n) for n in Nl]
+        delays = np.concatenate([np.zeros((M, 1)), rng.uniform(0, 5, (M, L - 1))], 1)
+        alpha, rho = rng.uniform(0.5, 2.0, (M, L)), rng.uniform(1.0, 6.0, M)
+        with gp.Objective(t, y, s, kern, marginalise_b=mb, precision=prec) as obj:
+            ll, info = obj.loglik_batch(delays, alpha, rho)
+        ref, rinfo = oracle.loglik_batch(kern, t, y, s, delays, alpha, rho, mb)
+        assert (rinfo == 0).all() and np.array_equal(info, rinfo), (Nl, kern, info, rinfo)
+        assert np.max(np.abs(ll - ref) / np.abs(ref)) <= tol, (Nl, kern, mb, prec)
+    with pytest.raises(gp.GpccError):
+        gp.Objective([np.arange(3.0)] * 9, [np.arange(3.0)] * 9, [np.ones(3)] * 9, "OU")
+    with pytest.raises(gp.GpccError):
+        gp.Objective([np.arange(1.0)], [np.arange(1.0)], [np.ones(1)], "OU", marginalise_b=True)
