@@ -358,9 +358,13 @@ static int enqueue_group(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, 
 }
 
 template <typename T>
-static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s)
+static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g_in, hipStream_t s)
 {
-    const int cnt8 = 8 * ((g.cnt + 7) / 8);
+    // a handful of evaluations (one objective(alpha, rho), predictTest, postb): spread every evaluation's jobs over
+    // the 8 XCDs; the usual mapping keeps an evaluation on the XCD blockIdx % 8 selects, 1/8 of the chip for one matrix
+    GpccGroup g = g_in;
+    g.spread = (g.cnt < 8 && !c.share_p) ? 1 : 0;
+    const int cnt8 = g.spread ? g.cnt : 8 * ((g.cnt + 7) / 8);
     // small groups (the single objective(alpha, rho) call): right-looking, many short jobs per step
     const bool right = (g.cnt <= h->right_looking_max) && (c.nt_fact == c.nt) && !c.share_p;
     const int p = c.share_p;   // shared prefix: steps k < p only involve the leader's rows < p and everyone's rows >= p
@@ -429,6 +433,7 @@ extern "C" int gpcc_loglik_batch_device(gpcc_handle_t h, int M, const double *d_
         g.first = gi * cs;
         g.slot0 = s * cs;
         g.cnt = (M - g.first < cs) ? (M - g.first) : cs;
+        g.spread = 0;   // decided per launch sequence in enqueue_factor_t
         GpccCtx cg = c;
         if (h->share_now && h->share_tiles > 0 && h->share_tiles < h->nt && g.cnt > h->right_looking_max && g.cnt > 1)
             cg.share_p = h->share_tiles;
@@ -563,7 +568,7 @@ static int run_augmented(gpcc_handle_t h, const double *delays, const double *al
     if (e != hipSuccess) { a.release(); return fail(h, GPCC_ERR_HIP, "augmented run: %s", hipGetErrorString(e)); }
     GpccGroup g;
     g.delays = dd; g.alpha = da; g.rho = dr; g.out_loglik = h->d_out; g.out_info = h->d_oinfo;
-    g.first = 0; g.slot0 = 0; g.cnt = 1;
+    g.first = 0; g.slot0 = 0; g.cnt = 1; g.spread = 0;
     const bool was_prof = h->prof;
     h->prof = false;
     rc = enqueue_group(h, c, g, s, factor, true, 0);

@@ -89,6 +89,8 @@ struct GpccGroup {
     int first;  // index of this group's first evaluation in the batch arrays
     int slot0;  // first slot of the stream that runs this group
     int cnt;    // evaluations in this group
+    int spread; // fewer than 8 evaluations: job b -> (evaluation b % cnt, tile b / cnt), i.e. every evaluation's tiles
+                // go round all 8 XCDs instead of staying on the one XCD that blockIdx % 8 selects (set by the host)
 };
 
 __device__ __forceinline__ long gpcc_tile_off(int I, int J)
@@ -367,7 +369,8 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
     const int per = RIGHT ? nrem * (nrem + 1) / 2 : (shared ? c.nt - c.share_p : c.nt - k);
     const int nmain = 8 * ((g.cnt + 7) / 8) * per;
     const int x = blockIdx.x & 7, qq = blockIdx.x >> 3;
-    int m = (qq / per) * 8 + x;
+    int m = g.spread ? (int)blockIdx.x % g.cnt : (qq / per) * 8 + x;
+    const int jt = g.spread ? (int)blockIdx.x / g.cnt : qq % per;   // job of evaluation m
     int I, J;   // output tile (I,J); left-looking: J = k
     if (shared && (int)blockIdx.x >= nmain) {   // the leader's own rows k .. share_p-1
         m = 0;
@@ -376,17 +379,17 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
     } else if (m >= g.cnt) {
         return;
     } else if (shared) {
-        I = c.share_p + qq % per;
+        I = c.share_p + jt;
         J = k;
     } else if (RIGHT) {
-        const int j = qq % per;
+        const int j = jt;
         int a = (int)((sqrtf(8.0f * j + 1.0f) - 1.0f) * 0.5f);
         while (a * (a + 1) / 2 > j) --a;
         while ((a + 1) * (a + 2) / 2 <= j) ++a;
         I = k + 1 + a;
         J = k + 1 + (j - a * (a + 1) / 2);
     } else {
-        I = k + qq % per;
+        I = k + jt;
         J = k;
     }
     const int slot = g.slot0 + m;
@@ -483,14 +486,14 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_trsm(GpccCtx c, GpccGroup g
     const int per = shared ? c.nt - c.share_p : c.nt - k - 1;
     const int nmain = 8 * ((g.cnt + 7) / 8) * per;
     const int x = blockIdx.x & 7, qq = blockIdx.x >> 3;
-    int m = (qq / per) * 8 + x, I;
+    int m = g.spread ? (int)blockIdx.x % g.cnt : (qq / per) * 8 + x, I;
     if (shared && (int)blockIdx.x >= nmain) {   // the leader's own rows k+1 .. share_p-1
         m = 0;
         I = k + 1 + ((int)blockIdx.x - nmain);
     } else if (m >= g.cnt) {
         return;
     } else {
-        I = (shared ? c.share_p : k + 1) + qq % per;
+        I = (shared ? c.share_p : k + 1) + (g.spread ? (int)blockIdx.x / g.cnt : qq % per);
     }
     const int slot = g.slot0 + m;
     const int lslot = shared ? g.slot0 : slot;
@@ -590,23 +593,18 @@ __device__ __forceinline__ double gpcc_bcast(double v, int srclane)
     return __hiloint2double(hi, lo);
 }
 
-// sqrt(d) and 1/sqrt(d) from ONE v_rsq_f64 (about 2^-23 relative) by two coupled Goldschmidt steps and a final
-// residual correction of the root: both within 1-2 ulp, a third of the dependent instructions of sqrt() followed by
-// an IEEE division.  Pivots are O(sigma^2 .. alpha^2 N): no scaling for denormals; d <= 0 / NaN gives NaN (the
-// caller has flagged the pivot by then).
-__device__ __forceinline__ void gpcc_sqrt_rsqrt(double d, double &sq, double &inv)
+// 1/sqrt(d) from ONE v_rsq_f64 (about 2^-23 relative) and two Newton steps y <- y + y (1/2 - (d/2) y^2): within
+// about 1 ulp, a third of the instructions of sqrt() followed by an IEEE division.  The diagonal entry itself is then
+// L_jj = d / sqrt(d) (one more rounding).  Pivots are O(sigma^2 .. alpha^2 N): no scaling for denormals; d <= 0 / NaN
+// gives NaN (the caller has flagged the pivot by then).
+__device__ __forceinline__ double gpcc_rsqrt(double d)
 {
-    const double y = __builtin_amdgcn_rsq(d);
-    double g = d * y, h = 0.5 * y;
-    double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    const double e = __builtin_fma(-g, g, d);
-    sq = __builtin_fma(e, h, g);
-    inv = h + h;
+    const double hd = 0.5 * d;
+    double y = __builtin_amdgcn_rsq(d);
+    double r = __builtin_fma(-hd, y * y, 0.5);
+    y = __builtin_fma(y, r, y);
+    r = __builtin_fma(-hd, y * y, 0.5);
+    return __builtin_fma(y, r, y);
 }
 
 template <typename T>
@@ -683,7 +681,7 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
                 // ---- (A) 16x16 potf2 + inverse in registers.  Lanes 0-15: lane l owns row l of D (v[cc] = A[l][cc]);
                 // lanes 16-31: lane 16 + l owns column l of X = inv(L_D) (v[cc] = delta(cc, l) - sum_j L[cc][j] X[j][l]);
                 // lanes 32-63 shadow them.  Right-looking, ONE instruction stream for both: once column j of L is
-                // final, v[j] <- v[j] / L[j][j] is L[l][j] on an L lane and X[j][l] on an X lane, and the same
+                // final, v[j] <- v[j] / sqrt(d_j) is L[l][j] on an L lane and X[j][l] on an X lane, and the same
                 // v[cc] -= v[j] L[cc][j] (L[cc][j] broadcast once from lane cc) updates the trailing row and the
                 // running sums.  Entries above the diagonal of D are never read back (no masking needed).
                 const bool xl = q != 0;
@@ -698,13 +696,16 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
                 for (int j = 0; j < 16; ++j) {
                     const double d = gpcc_bcast(v[j], j);
                     if (!(d > 0.0) && bad == 0) bad = j + 1;  // also catches NaN
-                    double sq, inv;
-                    gpcc_sqrt_rsqrt(d, sq, inv);
-                    v[j] = (lane == j) ? sq : v[j] * inv;
+                    v[j] *= gpcc_rsqrt(d);   // lane j: L[j][j] = d / sqrt(d)
+                    if (j < 15) {
+                        // L[j+1][j] feeds the next pivot: v_readlane (short latency).  The other entries of the column go
+                        // through LDS (one masked store, uniform-address loads): a third of the instructions of 2
+                        // readlanes per value, and their round trip is off the pivot-to-pivot chain.
+                        sr[q == 0 ? lr : 16 + lane] = v[j];   // (the other lanes store to a dead area: no branch)
+                        const double lnx = gpcc_bcast(v[j], j + 1);
+                        v[j + 1] = __builtin_fma(-v[j], lnx, v[j + 1]);
 #pragma unroll
-                    for (int cc = j + 1; cc < 16; ++cc) {
-                        const double lcj = gpcc_bcast(v[j], cc);  // L[cc][j]
-                        v[cc] = __builtin_fma(-v[j], lcj, v[cc]);
+                        for (int cc = j + 2; cc < 16; ++cc) v[cc] = __builtin_fma(-v[j], sr[cc], v[cc]);
                     }
                 }
                 if (lane < 32) {
@@ -759,11 +760,26 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
                         for (int r = 0; r < 4; ++r) sT[(rfv[u] * 16 + q + 4 * r) * LD + cfv[u] * 16 + lr] = x[u][r];
                     }
             }
-            // ---- (X) row i = jp of inv(L): X[i][j] = -inv(D_i) sum_{m = j}^{i-1} L[i][m] X[m][j], j < i (rows < i
+        }
+        if (jb > 0) {
+            // ---- (X) row i = jb-1 of inv(L): X[i][j] = -inv(D_i) sum_{m = j}^{i-1} L[i][m] X[m][j], j < i (rows < i
             // are complete); the accumulator of the sum is directly the B operand of the product with inv(D_i).
-            // Off-diagonal blocks live transposed in the (dead) upper triangle of the LDS image.
-            const int i = jp;
-            for (int j = (w3 + 30 - (ntri - 1)) % 3; j < i; j += 3) {   // continues the round-robin of (C); ntri <= 28
+            // Off-diagonal blocks live transposed in the (dead) upper triangle of the LDS image.  Waves 1-3 continue
+            // the round-robin of (C); the last row (nothing left for wave 0 to factor) is dealt over all four waves
+            // by chain length: {0}, {1, 6}, {2, 5}, {3, 4}.
+            const int i = jb - 1;
+            int j0 = -1, j1 = -1;
+            if (jb == 8) {
+                j0 = wave;
+                j1 = wave ? 7 - wave : -1;
+            } else if (wave != 0) {
+                const int nbx = 8 - jb, ntx = nbx * (nbx + 1) / 2;     // (C) of this step had ntx - 1 blocks for waves 1-3
+                j0 = (wave - 1 + 30 - (ntx - 1)) % 3;                   // ntx <= 28
+                j1 = j0 + 3;
+            }
+            for (int n = 0; n < 2; ++n) {
+                const int j = n ? j1 : j0;
+                if (j < 0 || j >= i) continue;
                 d4 S = {0.0, 0.0, 0.0, 0.0}, S1 = {0.0, 0.0, 0.0, 0.0};   // two chains: half the dependent MFMA latency
                 for (int mm = j; mm < i; ++mm) {
 #pragma unroll

@@ -1,3 +1,5 @@
+"""Cycle stamps (s_memtime) of one gpcc_diag_factor workgroup -- needs a library built with the STAMP patch
+(/tmp/stamp_patch3.py style instrumentation; not part of the product build)."""
 import sys, ctypes; sys.path.insert(0, ".")
 import numpy as np, torch
 torch.cuda.init()
@@ -16,15 +18,13 @@ for M in (1, 256):
     lib.gpcc_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
     assert lib.gpcc_debug_stamps(buf, 64) == 0
     st = np.array(list(buf), dtype=np.int64)
-    tot = st[38] - st[0]
-    print("M=%d total %d ticks (100 MHz -> %.1f us)" % (M, tot, tot / 100.0))
+    print("M=%d total %d cycles" % (M, st[23] - st[0]))
     print(" load            %6d" % (st[1] - st[0]))
     for jb in range(8):
-        b = 1 + jb * 4
-        nxt = st[b + 4] if jb < 7 else st[33]
-        print(" jb%d potf2+inv %5d store %5d panel %5d trailing %5d" % (jb, st[b+1]-st[b], st[b+2]-st[b+1], st[b+3]-st[b+2], nxt - st[b+3]))
-    print(" log+invlevels   %6d" % (st[34] - st[33]))
-    print(" W               %6d" % (st[35] - st[34]))
-    print(" gram            %6d" % (st[36] - st[35]))
-    print(" logdet/final    %6d" % (st[37] - st[36]))
-    print(" store           %6d" % (st[38] - st[37]))
+        print(" jb%d  A(jb)|C,X(jb-1) %5d   B(jb) %5d" % (jb, st[2 + 2 * jb] - st[1 + 2 * jb], st[3 + 2 * jb] - st[2 + 2 * jb]))
+    print(" X row 7         %6d" % (st[18] - st[17]))
+    print(" log             %6d" % (st[19] - st[18]))
+    print(" W               %6d" % (st[20] - st[19]))
+    print(" gram+logdet     %6d" % (st[21] - st[20]))
+    print(" final           %6d" % (st[22] - st[21]))
+    print(" store           %6d" % (st[23] - st[22]))
