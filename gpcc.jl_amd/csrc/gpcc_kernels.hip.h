@@ -615,14 +615,16 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int LD = GPCC_DIAG_LD, DLD = GPCC_DINV_LD;
     double *sT = smem;                          // 128 x LD: lower = A -> L ; upper = inv(L)^T off-diagonal blocks
-    double *sDinv = sT + GPCC_TILE * LD;        // 8 x 16 x DLD: inverses of the 16x16 diagonal blocks
+    double *sDinv = sT + GPCC_TILE * LD;        // 8 x 16 x DLD: inverses X_b of the 16x16 diagonal blocks, TRANSPOSED:
+                                                // X_b[r][c] at sDinv[(16 b + c) DLD + r] (a column of X_b is contiguous)
     double *sz = sDinv + 8 * 16 * DLD;          // nrhs x 128: Z_k, later W_k
-    double *sr = sz + GPCC_MAXRHS * GPCC_TILE;  // 128 log L_ii
+    double *sr = sz + GPCC_MAXRHS * GPCC_TILE;  // [0, 80): wave 0's column scratch in (A); [96, 104): prod 1/L_jj per 16-block
     double *sG = sr + GPCC_TILE;                // nrhs x nrhs Gram matrix
     double *sld = sG + GPCC_MAXRHS * GPCC_MAXRHS;   // sum log L_ii of this block
     int *sbad = (int *)(sG + GPCC_MAXRHS * GPCC_MAXRHS + 1);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: wave-indexed loops and addresses stay scalar
     const int m = blockIdx.x, slot = g.slot0 + m, nrhs = c.nrhs;
     const bool last = (k == c.nt_fact - 1);
     int inf = c.info[slot];
@@ -683,20 +685,21 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
                 // lanes 32-63 shadow them.  Right-looking, ONE instruction stream for both: once column j of L is
                 // final, v[j] <- v[j] / sqrt(d_j) is L[l][j] on an L lane and X[j][l] on an X lane, and the same
                 // v[cc] -= v[j] L[cc][j] (L[cc][j] broadcast once from lane cc) updates the trailing row and the
-                // running sums.  Entries above the diagonal of D are never read back (no masking needed).
+                // running sums.  Entries right of the diagonal of D are never used (no masking on load, update or store).
                 const bool xl = q != 0;
                 double v[16];
+                const double *row = sT + (r0 + lr) * LD + r0;   // 16 contiguous doubles, 16-byte aligned
 #pragma unroll
-                for (int cc = 0; cc < 16; ++cc) {
-                    const double lv = sT[(r0 + lr) * LD + r0 + ((cc <= lr) ? cc : 0)];
-                    v[cc] = xl ? ((cc == lr) ? 1.0 : 0.0) : ((cc <= lr) ? lv : 0.0);
-                }
+                for (int cc = 0; cc < 16; ++cc) v[cc] = xl ? ((cc == lr) ? 1.0 : 0.0) : row[cc];
                 int bad = 0;
+                double py = 1.0;   // |log10 L_jj| < 19 keeps the product of 16 inside fp64
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const double d = gpcc_bcast(v[j], j);
                     if (!(d > 0.0) && bad == 0) bad = j + 1;  // also catches NaN
-                    v[j] *= gpcc_rsqrt(d);   // lane j: L[j][j] = d / sqrt(d)
+                    const double y = gpcc_rsqrt(d);
+                    py *= y;                 // off the chain: sum log L_jj of the block = -log prod 1/sqrt(d_j)
+                    v[j] *= y;               // lane j: L[j][j] = d / sqrt(d)
                     if (j < 15) {
                         // L[j+1][j] feeds the next pivot: v_readlane (short latency).  The other entries of the column go
                         // through LDS (one masked store, uniform-address loads): a third of the instructions of 2
@@ -709,12 +712,13 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
                     }
                 }
                 if (lane < 32) {
-                    double *dst = xl ? (sDinv + (jb * 16) * DLD + lr) : (sT + (r0 + lr) * LD + r0);
-                    const int st = xl ? DLD : 1;
+                    // row l of L_D (its entries right of the diagonal are dead values in a dead area) resp. column l of
+                    // X (exact zeros above the diagonal): 16 contiguous stores from every lane, no masks
+                    double *dst = xl ? (sDinv + (jb * 16 + lr) * DLD) : (sT + (r0 + lr) * LD + r0);
 #pragma unroll
-                    for (int cc = 0; cc < 16; ++cc)
-                        if (xl || cc <= lr) dst[cc * st] = v[cc];   // L_D (lower) resp. X[cc][l] (zero above the diagonal)
+                    for (int cc = 0; cc < 16; ++cc) dst[cc] = v[cc];
                     if (lane == 0 && bad && *sbad == 0) *sbad = r0 + bad;
+                    if (lane == 0) sr[96 + jb] = py;
                 }
             }
         } else if (jb > 0) {
@@ -731,8 +735,7 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
                     const int tt = t0 + 3 * u;
                     on[u] = tt < ntri;
                     const int te = on[u] ? tt : t0;
-                    int rr = 0;
-                    while ((rr + 1) * (rr + 2) / 2 <= te) ++rr;
+                    const int rr = (te >= 1) + (te >= 3) + (te >= 6) + (te >= 10) + (te >= 15) + (te >= 21);   // te < 28
                     rfv[u] = jp + 1 + rr;
                     cfv[u] = jp + 1 + te - rr * (rr + 1) / 2;
                 }
@@ -764,18 +767,57 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
         if (jb > 0) {
             // ---- (X) row i = jb-1 of inv(L): X[i][j] = -inv(D_i) sum_{m = j}^{i-1} L[i][m] X[m][j], j < i (rows < i
             // are complete); the accumulator of the sum is directly the B operand of the product with inv(D_i).
-            // Off-diagonal blocks live transposed in the (dead) upper triangle of the LDS image.  Waves 1-3 continue
-            // the round-robin of (C); the last row (nothing left for wave 0 to factor) is dealt over all four waves
-            // by chain length: {0}, {1, 6}, {2, 5}, {3, 4}.
+            // Off-diagonal blocks live transposed in the (dead) upper triangle of the LDS image.
+            // ---- (W) rows i of W_k = inv(L_kk) Z_k by forward substitution, W_i = inv(D_i) (Z_i - sum_{m<i} L[i][m] W_m):
+            // the same two products with the right-hand sides (padded to 16 columns) in place of X[m][j]; in place in sz.
+            // Dealt by chain length (units = products of 16x16 blocks): waves 1-3 take {W, 4, 5}, {0, 3}, {1, 2};
+            // the last row (nothing left for wave 0 to factor) goes over all four waves: {W, 6}, {0, 5}, {1, 4}, {2, 3}.
             const int i = jb - 1;
+            bool dow = false;
             int j0 = -1, j1 = -1;
             if (jb == 8) {
-                j0 = wave;
-                j1 = wave ? 7 - wave : -1;
+                dow = wave == 0;
+                j0 = wave ? wave - 1 : 6;
+                j1 = wave ? 6 - wave : -1;
+            } else if (wave == 1) {
+                dow = true;
+                j0 = 4;
+                j1 = 5;
             } else if (wave != 0) {
-                const int nbx = 8 - jb, ntx = nbx * (nbx + 1) / 2;     // (C) of this step had ntx - 1 blocks for waves 1-3
-                j0 = (wave - 1 + 30 - (ntx - 1)) % 3;                   // ntx <= 28
-                j1 = j0 + 3;
+                j0 = wave - 2;    // wave 2: {0, 3}, wave 3: {1, 2}
+                j1 = 5 - wave;
+            }
+            if (dow) {
+                const int zrow = (lr < nrhs) ? lr : 0;
+                d4 S, S1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double zv = sz[zrow * GPCC_TILE + i * 16 + q + 4 * r];
+                    S[r] = (lr < nrhs) ? -zv : 0.0;
+                }
+                for (int mm = 0; mm < i; ++mm) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) {
+                        const double av = sT[(i * 16 + lr) * LD + mm * 16 + q + 4 * s2];   // L[i][mm]
+                        const double wv = sz[zrow * GPCC_TILE + mm * 16 + q + 4 * s2];      // W_mm[k][rhs lr]
+                        const double bv = (lr < nrhs) ? wv : 0.0;
+                        if (s2 & 1) S1 = PD::mfma(av, bv, S1);
+                        else S = PD::mfma(av, bv, S);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[r] += S1[r];
+                d4 Y = {0.0, 0.0, 0.0, 0.0}, Y1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double dv = -sDinv[(i * 16 + q + 4 * r) * DLD + lr];
+                    if (r & 1) Y1 = PD::mfma(dv, S[r], Y1);
+                    else Y = PD::mfma(dv, S[r], Y);
+                }
+                if (lr < nrhs) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sz[lr * GPCC_TILE + i * 16 + q + 4 * r] = Y[r] + Y1[r];
+                }
             }
             for (int n = 0; n < 2; ++n) {
                 const int j = n ? j1 : j0;
@@ -785,7 +827,7 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
 #pragma unroll
                     for (int s2 = 0; s2 < 4; ++s2) {
                         const double av = sT[(i * 16 + lr) * LD + mm * 16 + q + 4 * s2];               // L[i][mm]
-                        const double bv = (mm == j) ? sDinv[(j * 16 + q + 4 * s2) * DLD + lr]          // X[j][j][k][c]
+                        const double bv = (mm == j) ? sDinv[(j * 16 + lr) * DLD + q + 4 * s2]          // X[j][j][k][c]
                                                     : sT[(j * 16 + lr) * LD + mm * 16 + q + 4 * s2];   // X[mm][j]^T
                         if (s2 & 1) S1 = PD::mfma(av, bv, S1);
                         else S = PD::mfma(av, bv, S);
@@ -796,7 +838,7 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
                 d4 Y = {0.0, 0.0, 0.0, 0.0}, Y1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {  // the accumulator S (row q+4r, col lr) IS the B operand of k-step r
-                    const double dv = -sDinv[(i * 16 + lr) * DLD + q + 4 * r];
+                    const double dv = -sDinv[(i * 16 + q + 4 * r) * DLD + lr];
                     if (r & 1) Y1 = PD::mfma(dv, S[r], Y1);
                     else Y = PD::mfma(dv, S[r], Y);
                 }
@@ -812,7 +854,7 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) {
                 av[s2] = sT[(rf * 16 + lr) * LD + r0 + q + 4 * s2];
-                bv[s2] = sDinv[(jb * 16 + lr) * DLD + q + 4 * s2];   // B[k][c] = inv(D)[c][k]
+                bv[s2] = sDinv[(jb * 16 + q + 4 * s2) * DLD + lr];   // B[k][c] = inv(D)[c][k]
             }
             d4 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -822,40 +864,7 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
         }
         __syncthreads();
     }
-    if (tid < GPCC_TILE) sr[tid] = log(sT[tid * LD + tid]);
-    __syncthreads();
-    // ---- W_k = X Z_k for every right-hand side, by MFMA: A = rows of X (off-diagonal blocks from the transposed
-    // image, diagonal block from sDinv), B = Z^T padded to 16 columns; wave w takes the 16-row blocks w and 7 - w
-    d4 wacc[2];
-#pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2) {
-        const int bi = t2 ? 7 - wave : wave;
-        const int zrow = (lr < nrhs) ? lr : 0;
-        d4 w0 = {0.0, 0.0, 0.0, 0.0}, w1 = {0.0, 0.0, 0.0, 0.0};
-        for (int kb = 0; kb <= bi; ++kb) {
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                const int kk = kb * 16 + q + 4 * s2;
-                const double av = (kb < bi) ? sT[kk * LD + bi * 16 + lr] : sDinv[(bi * 16 + lr) * DLD + q + 4 * s2];
-                const double zv = sz[zrow * GPCC_TILE + kk];
-                const double bv = (lr < nrhs) ? zv : 0.0;
-                if (s2 & 1) w1 = PD::mfma(av, bv, w1);
-                else w0 = PD::mfma(av, bv, w0);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) wacc[t2][r] = w0[r] + w1[r];
-    }
-    __syncthreads();   // every wave has read Z_k
-    if (lr < nrhs) {
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-            const int bi = t2 ? 7 - wave : wave;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sz[lr * GPCC_TILE + bi * 16 + q + 4 * r] = wacc[t2][r];
-        }
-    }
-    __syncthreads();
+    // sz now holds W_k
     for (int e = tid; e < nrhs * GPCC_TILE; e += 256)
         c.w[((long)slot * nrhs + e / GPCC_TILE) * c.Np + k * GPCC_TILE + (e % GPCC_TILE)] = sz[e];
     // Gram matrix W^T W (accumulated over the steps) and sum log L_ii: one wave per entry, fixed reduction tree
@@ -873,7 +882,7 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
         }
     }
     if (wave == 3) {
-        double pr = sr[lane] + sr[lane + 64];
+        double pr = (lane < 8) ? -log(sr[96 + (lane & 7)]) : 0.0;   // sum log L_jj per 16-block
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) pr += __shfl_xor(pr, o);
         if (lane == 0) *sld = pr;
@@ -930,7 +939,9 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
     }
     // ---- write inv(L_kk) (B operand of the panel solve) and L_kk, both in tile layout
     T *Linv = (T *)c.linv + (long)slot * GPCC_TILE_ELEMS;
-    for (int p0 = tid; p0 < NPIECE; p0 += 256) {   // 16-byte stores
+    const bool store_l = c.store_l != 0;   // L_kk is read by nobody on the log-likelihood path (dense export only)
+#pragma unroll 4
+    for (int p0 = tid; p0 < NPIECE; p0 += 256) {   // 16-byte stores; unconditional LDS reads (address select), masked after
         const int e = p0 * P::EP;
         const int ch = e / (GPCC_TILE * P::KC), rem = e % (GPCC_TILE * P::KC), r = rem / P::KC, ks = rem % P::KC;
         const int col0 = ch * P::KC + ((ks / P::EP) ^ gpcc_sw(r)) * P::EP;
@@ -938,16 +949,16 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
 #pragma unroll
         for (int h = 0; h < P::EP; ++h) {
             const int col = col0 + h;
-            double xv = 0.0, lv = 0.0;
-            if (col <= r) {
-                xv = ((col >> 4) == (r >> 4)) ? sDinv[r * DLD + (col & 15)] : sT[col * LD + r];
-                lv = sT[r * LD + col];
-            }
-            xo[h] = (T)xv;
-            lo[h] = (T)lv;
+            const double *src = ((col >> 4) == (r >> 4)) ? sDinv + ((r & ~15) + (col & 15)) * DLD + (r & 15) : sT + col * LD + r;
+            const double xv = *src;
+            xo[h] = (T)((col <= r) ? xv : 0.0);
         }
         *(typename P::v16 *)(Linv + e) = xo;
-        if (c.store_l) *(typename P::v16 *)(Tt + e) = lo;   // L_kk is read by nobody on the log-likelihood path (dense export only)
+        if (store_l) {
+#pragma unroll
+            for (int h = 0; h < P::EP; ++h) lo[h] = (T)((col0 + h <= r) ? sT[r * LD + col0 + h] : 0.0);
+            *(typename P::v16 *)(Tt + e) = lo;
+        }
     }
 }
 

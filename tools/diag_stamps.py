@@ -23,8 +23,8 @@ for M in (1, 256):
     for jb in range(8):
         print(" jb%d  A(jb)|C,X(jb-1) %5d   B(jb) %5d" % (jb, st[2 + 2 * jb] - st[1 + 2 * jb], st[3 + 2 * jb] - st[2 + 2 * jb]))
     print(" X row 7         %6d" % (st[18] - st[17]))
-    print(" log             %6d" % (st[19] - st[18]))
-    print(" W               %6d" % (st[20] - st[19]))
+    print(" (after loop)    %6d" % (st[19] - st[18]))
+    print(" W store         %6d" % (st[20] - st[19]))
     print(" gram+logdet     %6d" % (st[21] - st[20]))
     print(" final           %6d" % (st[22] - st[21]))
     print(" store           %6d" % (st[23] - st[22]))
