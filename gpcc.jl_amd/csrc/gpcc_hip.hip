@@ -376,7 +376,7 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
         }
         {
             ProfScope pr(h, GPCC_PROF_DIAG, s);
-            gpcc_diag_factor<T><<<(k < p) ? 1 : g.cnt, 256, GPCC_DIAG_LDS_BYTES, s>>>(c, g, k);
+            gpcc_diag_factor<T><<<(k < p) ? 1 : g.cnt, GPCC_DIAG_THREADS, GPCC_DIAG_LDS_BYTES, s>>>(c, g, k);
         }
         if (k < c.nt - 1) {
             ProfScope pr(h, GPCC_PROF_TRSM, s);

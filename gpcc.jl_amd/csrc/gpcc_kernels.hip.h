@@ -18,6 +18,7 @@
 #define GPCC_CHUNK_BYTES 16384
 #define GPCC_MAXL 8
 #define GPCC_MAXRHS (GPCC_MAXL + 1)
+#define GPCC_DIAG_THREADS 512
 #define GPCC_DIAG_LD 130
 #define GPCC_DINV_LD 17
 #define GPCC_DIAG_LDS_BYTES \
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_trsm(GpccCtx c, GpccGroup g
 }
 
 // ------------------------------------------------------------------------------------------
-// gpcc_diag_factor: step k's 128x128 diagonal block, one workgroup (4 waves) per evaluation, all in
+// gpcc_diag_factor: step k's 128x128 diagonal block, one workgroup (8 waves) per evaluation, all in
 // LDS and ALWAYS in fp64 (an fp32 tile is widened on load, inv(L_kk) and L_kk are rounded on store):
 // blocked dpotf2 (16-wide panels), its triangular inverse (the B operand of the MFMA panel
 // solve), sum log L_ii (logdet of PDMat), W_k = inv(L_kk) Z_k and the Gram matrix W^T W (sqmahal);
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_trsm(GpccCtx c, GpccGroup g
 //   rows of L and columns of the inverse, broadcasts by v_readlane);  (B) panel rows below: P = A inv(D)^T by
 //   MFMA;  (C) trailing update C -= P P^T by MFMA;  (X) row jb of inv(L) block-wise by MFMA: the accumulator
 //   of S = sum_m L[i][m] X[m][j] is directly the B operand of X[i][j] = -inv(D_i) S.  Software-pipelined:
-//   (A) of block jb+1 runs on wave 0 while waves 1-3 do (C) and (X) of block jb.
+//   (A) of block jb+1 runs on wave 0 while six worker waves do (C), (X) and the forward substitution (W) of block jb.
 //   X's off-diagonal blocks live transposed in the (dead) upper triangle of the LDS image.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ double gpcc_bcast(double v, int srclane)
@@ -608,7 +609,7 @@ __device__ __forceinline__ double gpcc_rsqrt(double d)
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, int k)
+__global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c, GpccGroup g, int k)
 {
     typedef GpccPrec<T> P;
     typedef GpccPrec<double> PD;
@@ -625,6 +626,11 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
 
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: wave-indexed loops and addresses stay scalar
+    // Eight waves = two per SIMD: one wave alone issues an f64 MFMA only every ~139 cycles (profiles/r01/microbench_fp64.log),
+    // two keep the pipe busy.  Wave 0 runs the register factorisations (A); wave 4 shares its SIMD and stays out of its
+    // way; the other six are the MFMA workers of (C), (X), (W).
+    constexpr int NWK = 6;
+    const int wk = (wave == 0 || wave == 4) ? -1 : (wave < 4 ? wave - 1 : wave - 2);
     const int m = blockIdx.x, slot = g.slot0 + m, nrhs = c.nrhs;
     const bool last = (k == c.nt_fact - 1);
     int inf = c.info[slot];
@@ -638,29 +644,32 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
     }
     T *tiles = (T *)c.tiles + (long)slot * c.slot_stride;
     T *Tt = tiles + gpcc_tile_off(k, k);
-    // 16-byte pieces, 16 loads in flight per thread (one load per iteration would serialise 64 HBM round trips)
+    // 16-byte pieces, all of a thread's loads in flight (one load per iteration would serialise the HBM round trips)
     constexpr int NPIECE = GPCC_TILE_ELEMS / P::EP;   // pieces per tile
-    for (int p0 = tid; p0 < NPIECE; p0 += 256 * 16) {
-        typename P::v16 v[16];
+    constexpr int NT = GPCC_DIAG_THREADS;
+    constexpr int UL = (NPIECE / NT < 16) ? NPIECE / NT : 16;   // loads in flight per thread (fp64: 16, fp32: 8)
+    static_assert(NPIECE % (NT * UL) == 0, "tile pieces must divide evenly over the threads");
+    for (int p0 = tid; p0 < NPIECE; p0 += NT * UL) {
+        typename P::v16 v[UL];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = *(const typename P::v16 *)(Tt + (long)(p0 + 256 * u) * P::EP);
+        for (int u = 0; u < UL; ++u) v[u] = *(const typename P::v16 *)(Tt + (long)(p0 + NT * u) * P::EP);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int e = (p0 + 256 * u) * P::EP;   // storage position of the piece's first element
+        for (int u = 0; u < UL; ++u) {
+            const int e = (p0 + NT * u) * P::EP;   // storage position of the piece's first element
             const int ch = e / (GPCC_TILE * P::KC), rem = e % (GPCC_TILE * P::KC), r = rem / P::KC, ks = rem % P::KC;
             const int kk = ((ks / P::EP) ^ gpcc_sw(r)) * P::EP;
 #pragma unroll
             for (int h = 0; h < P::EP; ++h) sT[r * LD + ch * P::KC + kk + h] = (double)v[u][h];
         }
     }
-    for (int e = tid; e < nrhs * GPCC_TILE; e += 256)
+    for (int e = tid; e < nrhs * GPCC_TILE; e += NT)
         sz[e] = c.z[((long)slot * nrhs + e / GPCC_TILE) * c.Np + k * GPCC_TILE + (e % GPCC_TILE)];
     if (tid == 0) *sbad = 0;
 
     __syncthreads();   // tile and right-hand sides are in LDS
     // Software pipeline over the eight 16-column blocks.  Step jb: wave 0 folds column block jb-1 into the next
-    // diagonal block and factors it (A), while waves 1-3 finish the trailing update of column block jb-1 (C) and
-    // build row jb-1 of inv(L) (X); then all four waves form the panel of column block jb (B).
+    // diagonal block and factors it (A), while the workers finish the trailing update of column block jb-1 (C) and
+    // build row jb-1 of inv(L) (X) and of W; then all waves form the panel of column block jb (B).
     for (int jb = 0; jb <= 8; ++jb) {
         const int r0 = jb * 16, rp = r0 - 16;   // rp: first column of the previous block
         if (wave == 0) {
@@ -721,18 +730,18 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
                     if (lane == 0) sr[96 + jb] = py;
                 }
             }
-        } else if (jb > 0) {
-            const int w3 = wave - 1, jp = jb - 1;
+        } else if (wk >= 0 && jb > 0) {
+            const int jp = jb - 1;
             // ---- (C) rest of the trailing update of column block jp: C[rf][cf] -= P_rf P_cf^T, jp < cf <= rf, block
             // t = rr (rr+1)/2 + cc2 of the (7 - jp)-row triangle; t = 0 is wave 0's.  Two blocks at a time
             // (independent MFMA chains, all LDS reads of a pair in flight together).
             const int nb = 7 - jp, ntri = nb * (nb + 1) / 2;
-            for (int t0 = 1 + w3; t0 < ntri; t0 += 6) {
+            for (int t0 = 1 + wk; t0 < ntri; t0 += 2 * NWK) {
                 int rfv[2], cfv[2];
                 bool on[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int tt = t0 + 3 * u;
+                    const int tt = t0 + NWK * u;
                     on[u] = tt < ntri;
                     const int te = on[u] ? tt : t0;
                     const int rr = (te >= 1) + (te >= 3) + (te >= 6) + (te >= 10) + (te >= 15) + (te >= 21);   // te < 28
@@ -770,22 +779,18 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
             // Off-diagonal blocks live transposed in the (dead) upper triangle of the LDS image.
             // ---- (W) rows i of W_k = inv(L_kk) Z_k by forward substitution, W_i = inv(D_i) (Z_i - sum_{m<i} L[i][m] W_m):
             // the same two products with the right-hand sides (padded to 16 columns) in place of X[m][j]; in place in sz.
-            // Dealt by chain length (units = products of 16x16 blocks): waves 1-3 take {W, 4, 5}, {0, 3}, {1, 2};
-            // the last row (nothing left for wave 0 to factor) goes over all four waves: {W, 6}, {0, 5}, {1, 4}, {2, 3}.
+            // One task per worker (the two shortest share one); the last row (nothing left for wave 0 to factor) goes
+            // over all eight waves.
             const int i = jb - 1;
             bool dow = false;
             int j0 = -1, j1 = -1;
-            if (jb == 8) {
+            if (jb == 8) {          // all eight waves, one task each: W, X_0 .. X_6
                 dow = wave == 0;
-                j0 = wave ? wave - 1 : 6;
-                j1 = wave ? 6 - wave : -1;
-            } else if (wave == 1) {
-                dow = true;
-                j0 = 4;
-                j1 = 5;
-            } else if (wave != 0) {
-                j0 = wave - 2;    // wave 2: {0, 3}, wave 3: {1, 2}
-                j1 = 5 - wave;
+                j0 = wave - 1;
+            } else if (wk >= 0) {   // tasks W, X_0, .., X_{i-1} (i <= 6) on the six workers; the two shortest share one
+                dow = wk == 0;
+                j0 = wk - 1;
+                j1 = (wk == NWK - 1) ? NWK - 1 : -1;
             }
             if (dow) {
                 const int zrow = (lr < nrhs) ? lr : 0;
@@ -849,7 +854,7 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
         __syncthreads();
         if (jb == 8) break;
         // ---- (B) panel of column block jb: P = A[rf, jb] inv(D_jb)^T for the row fragments below, in place
-        for (int rf = jb + 1 + wave; rf < 8; rf += 4) {
+        for (int rf = jb + 1 + wave; rf < 8; rf += NT / 64) {
             double av[4], bv[4];
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) {
@@ -865,10 +870,10 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
         __syncthreads();
     }
     // sz now holds W_k
-    for (int e = tid; e < nrhs * GPCC_TILE; e += 256)
+    for (int e = tid; e < nrhs * GPCC_TILE; e += NT)
         c.w[((long)slot * nrhs + e / GPCC_TILE) * c.Np + k * GPCC_TILE + (e % GPCC_TILE)] = sz[e];
     // Gram matrix W^T W (accumulated over the steps) and sum log L_ii: one wave per entry, fixed reduction tree
-    for (int e = wave; e < nrhs * nrhs; e += 4) {
+    for (int e = wave; e < nrhs * nrhs; e += NT / 64) {
         const int ga = e / nrhs, gb = e % nrhs;
         double pr = sz[ga * GPCC_TILE + lane] * sz[gb * GPCC_TILE + lane] +
                     sz[ga * GPCC_TILE + 64 + lane] * sz[gb * GPCC_TILE + 64 + lane];
@@ -891,7 +896,7 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
     if (c.share_p && k == c.share_p - 1) {
         // last step of the shared prefix (only the leader runs it): hand sum log L_ii and W'W over to the followers
         const double ldp = *sld + c.logdet[slot];   // same expression as the per-evaluation path below (bitwise identical results)
-        for (int f = 1 + tid; f < g.cnt; f += 256) {
+        for (int f = 1 + tid; f < g.cnt; f += NT) {
             c.logdet[g.slot0 + f] = ldp;
             for (int i = 0; i < nrhs * nrhs; ++i) c.gram[(long)(g.slot0 + f) * GPCC_MAXRHS * GPCC_MAXRHS + i] = sG[i];
         }
@@ -941,7 +946,7 @@ __global__ __launch_bounds__(256) void gpcc_diag_factor(GpccCtx c, GpccGroup g, 
     T *Linv = (T *)c.linv + (long)slot * GPCC_TILE_ELEMS;
     const bool store_l = c.store_l != 0;   // L_kk is read by nobody on the log-likelihood path (dense export only)
 #pragma unroll 4
-    for (int p0 = tid; p0 < NPIECE; p0 += 256) {   // 16-byte stores; unconditional LDS reads (address select), masked after
+    for (int p0 = tid; p0 < NPIECE; p0 += NT) {   // 16-byte stores; unconditional LDS reads (address select), masked after
         const int e = p0 * P::EP;
         const int ch = e / (GPCC_TILE * P::KC), rem = e % (GPCC_TILE * P::KC), r = rem / P::KC, ks = rem % P::KC;
         const int col0 = ch * P::KC + ((ks / P::EP) ^ gpcc_sw(r)) * P::EP;
