@@ -619,7 +619,7 @@ __global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c,
     double *sDinv = sT + GPCC_TILE * LD;        // 8 x 16 x DLD: inverses X_b of the 16x16 diagonal blocks, TRANSPOSED:
                                                 // X_b[r][c] at sDinv[(16 b + c) DLD + r] (a column of X_b is contiguous)
     double *sz = sDinv + 8 * 16 * DLD;          // nrhs x 128: Z_k, later W_k
-    double *sr = sz + GPCC_MAXRHS * GPCC_TILE;  // [0, 80): wave 0's column scratch in (A); [96, 104): prod 1/L_jj per 16-block
+    double *sr = sz + GPCC_MAXRHS * GPCC_TILE;  // [0, 80): wave 0's column scratch in (A); [96, 112): prod 1/L_jj per 16-block (mantissa, exponent)
     double *sG = sr + GPCC_TILE;                // nrhs x nrhs Gram matrix
     double *sld = sG + GPCC_MAXRHS * GPCC_MAXRHS;   // sum log L_ii of this block
     int *sbad = (int *)(sG + GPCC_MAXRHS * GPCC_MAXRHS + 1);
@@ -701,13 +701,15 @@ __global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c,
 #pragma unroll
                 for (int cc = 0; cc < 16; ++cc) v[cc] = xl ? ((cc == lr) ? 1.0 : 0.0) : row[cc];
                 int bad = 0;
-                double py = 1.0;   // |log10 L_jj| < 19 keeps the product of 16 inside fp64
+                double py = 1.0;   // prod of the mantissas of 1/sqrt(d_j) (>= 2^-16) ...
+                int pe = 0;        // ... and the sum of their exponents: no overflow whatever the scale of K
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const double d = gpcc_bcast(v[j], j);
                     if (!(d > 0.0) && bad == 0) bad = j + 1;  // also catches NaN
                     const double y = gpcc_rsqrt(d);
-                    py *= y;                 // off the chain: sum log L_jj of the block = -log prod 1/sqrt(d_j)
+                    py *= __builtin_amdgcn_frexp_mant(y);   // off the chain: sum log L_jj of the block = -log prod 1/sqrt(d_j)
+                    pe += __builtin_amdgcn_frexp_exp(y);
                     v[j] *= y;               // lane j: L[j][j] = d / sqrt(d)
                     if (j < 15) {
                         // L[j+1][j] feeds the next pivot: v_readlane (short latency).  The other entries of the column go
@@ -727,7 +729,10 @@ __global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c,
 #pragma unroll
                     for (int cc = 0; cc < 16; ++cc) dst[cc] = v[cc];
                     if (lane == 0 && bad && *sbad == 0) *sbad = r0 + bad;
-                    if (lane == 0) sr[96 + jb] = py;
+                    if (lane == 0) {
+                        sr[96 + jb] = py;
+                        sr[104 + jb] = (double)pe;
+                    }
                 }
             }
         } else if (wk >= 0 && jb > 0) {
@@ -887,7 +892,8 @@ __global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c,
         }
     }
     if (wave == 3) {
-        double pr = (lane < 8) ? -log(sr[96 + (lane & 7)]) : 0.0;   // sum log L_jj per 16-block
+        double pr = 0.0;   // sum log L_jj per 16-block
+        if (lane < 8) pr = -(log(sr[96 + lane]) + sr[104 + lane] * 0.69314718055994530942);
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) pr += __shfl_xor(pr, o);
         if (lane == 0) *sld = pr;

@@ -692,3 +692,19 @@ def test_extreme_shapes(gp, oracle, prec, tol):
         gp.Objective([np.arange(3.0)] * 9, [np.arange(3.0)] * 9, [np.ones(3)] * 9, "OU")
     with pytest.raises(gp.GpccError):
         gp.Objective([np.arange(1.0)], [np.arange(1.0)], [np.ones(1)], "OU", marginalise_b=True)
+
+
+def test_extreme_scales_of_the_covariance(gp, oracle):
+    """Amplitudes far outside any sensible fit (K scaled by 1e-60 .. 1e+60: L_jj from 1e-30 to 1e+30): the diagonal kernel's
+    log-determinant (product of pivot reciprocals per 16-block, mantissa/exponent split) must neither overflow nor underflow."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([150, 130], seed=3)
+    for scale in (1e-30, 1e-12, 1.0, 1e12, 1e30):
+        ys = [a * scale for a in y]
+        ss = [a * scale for a in s]
+        alpha = np.array([[1.3 * scale, 0.9 * scale]])
+        with gp.Objective(t, ys, ss, gp.matern32) as obj:
+            ll, info = obj.loglik_batch([[0.0, 2.0]], alpha, [3.5])
+        ref, rinfo = oracle.loglik_batch("matern32", t, ys, ss, [[0.0, 2.0]], alpha, [3.5], True)
+        assert info[0] == 0 and rinfo[0] == 0 and np.isfinite(ll[0])
+        assert abs(ll[0] - ref[0]) <= 1e-9 * abs(ref[0]), (scale, ll[0], ref[0])
