@@ -17,7 +17,8 @@
  *   - ragged light curves are passed flattened in band order, user order inside a band
  *     (Y = reduce(vcat, yarray), src/gpccfixdelay_marginaliseb.jl:85).
  *   - per-evaluation parameter blocks are ROW-major M x L (Julia passes an L x M Matrix).
- *   - no callbacks, no retained caller pointers, all device memory owned by the handle;
+ *   - no callbacks on the likelihood path (only gpcc_neldermead_batch, the optimiser on its own, takes one), no
+ *     retained caller pointers, all device memory owned by the handle;
  *     one handle per thread/process; several handles (and processes) may share a GPU.
  *   - there is NO CPU fallback: without a HIP device every compute entry returns an error.
  */
