@@ -708,3 +708,19 @@ def test_extreme_scales_of_the_covariance(gp, oracle):
         ref, rinfo = oracle.loglik_batch("matern32", t, ys, ss, [[0.0, 2.0]], alpha, [3.5], True)
         assert info[0] == 0 and rinfo[0] == 0 and np.isfinite(ll[0])
         assert abs(ll[0] - ref[0]) <= 1e-9 * abs(ref[0]), (scale, ll[0], ref[0])
+
+
+@pytest.mark.parametrize("prec,mb,tol", [("fp32", True, FP32_RTOL), ("fp64", False, 1e-8), ("fp32", False, FP32_RTOL)])
+def test_native_grid_fit_other_handles(gp, oracle, prec, mb, tol):
+    """gpcc_grid_loglik over an fp32 handle and over the fixed-offset objective (gpccfixdelay.jl:131-139): the returned
+    value is the objective at the returned hyper-parameters, and the fit improved on its best random start."""
+    from gpcc_amd import fit, synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([80, 70], seed=4, span=25.0)
+    cand = np.stack([np.zeros(5), np.array([0.0, 1.0, 2.0, 3.0, 7.5])], 1)
+    with gp.Objective(t, y, s, gp.matern52, marginalise_b=mb, precision=prec) as obj:
+        res = fit.gpcc_grid(t, y, s, kernel=gp.matern52, candidatedelays=cand, iterations=60, rhomax=40.0, objective=obj)
+        start = fit.gpcc_grid(t, y, s, kernel=gp.matern52, candidatedelays=cand, iterations=0, rhomax=40.0, objective=obj)
+    ref, rinfo = oracle.loglik_batch("matern52", t, y, s, cand, res.alpha, res.rho, mb, nthreads=8)
+    assert (rinfo == 0).all() and np.max(np.abs(res.loglikel - ref) / np.abs(ref)) <= tol
+    assert np.all(res.loglikel >= start.loglikel - tol * np.abs(start.loglikel)) and np.any(res.loglikel > start.loglikel)
+    assert np.all(res.alpha > 0) and np.all((res.rho > 0.1) & (res.rho < 40.0))
