@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--n-per-band", type=int, default=2048)
     ap.add_argument("--bands", type=int, default=2, help="2 (default metric config) or 3 (cfg4: 2-D delay grid)")
     ap.add_argument("--kernel", default="matern32")
+    ap.add_argument("--seed", type=int, default=1, help="seed of the synthetic light curves (SURVEY 8(d): seeds 1, 2, 3)")
     ap.add_argument("--precision", default="fp64", choices=["fp64", "fp32"])
     ap.add_argument("--streams", type=int, default=None)
     ap.add_argument("--slots", type=int, default=None)
@@ -109,7 +110,7 @@ def main():
 
     Nb = args.n_per_band
     L = args.bands
-    t, y, s, _ = synthetic.simulate_lightcurves([Nb] * L, seed=1)
+    t, y, s, _ = synthetic.simulate_lightcurves([Nb] * L, seed=args.seed)
     alpha, rho = synthetic.default_hyperparameters(y)
     N = L * Nb
     G = args.grid
