@@ -724,3 +724,55 @@ def test_native_grid_fit_other_handles(gp, oracle, prec, mb, tol):
     assert (rinfo == 0).all() and np.max(np.abs(res.loglikel - ref) / np.abs(ref)) <= tol
     assert np.all(res.loglikel >= start.loglikel - tol * np.abs(start.loglikel)) and np.any(res.loglikel > start.loglikel)
     assert np.all(res.alpha > 0) and np.all((res.rho > 0.1) & (res.rho < 40.0))
+
+
+def test_c_abi_from_plain_c(gp, oracle, tmp_path):
+    """The boundary without Python or torch in the process: tests/abi/abi_smoke.c (plain C, gcc) links libgpcc_hip.so,
+    evaluates a small batch, normalises it, runs the native per-delay fit and provokes two errors; the printed numbers are
+    checked here against the oracle on the same closed-form light curves."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from gpcc_amd import build as gbuild
+    libdir = os.path.dirname(gbuild.LIB_PATH)
+    exe = str(tmp_path / "abi_smoke")
+    cc = subprocess.run(["gcc", "-O1", "-std=c99", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "abi", "abi_smoke.c"),
+                         "-o", exe, "-L", libdir, "-lgpcc_hip", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"],
+                        capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    lines = [ln.split() for ln in run.stdout.splitlines()]
+    assert lines[-1] == ["done"]
+    # the same light curves
+    N0, N1 = 150, 131
+    i = np.arange(N0 + N1)
+    band = (i >= N0).astype(int)
+    j = np.where(band == 1, i - N0, i).astype(float)
+    tt = np.fmod(7.3 * j + 0.37 * j * j, 50.0) + 0.01 * j
+    yy = np.where(band == 1, 15.0, 6.0) + np.where(band == 1, 1.5, 1.0) * np.sin(0.35 * (tt - np.where(band == 1, 2.0, 0.0))) \
+        + 0.3 * np.cos(12.9898 * i)
+    sg = 0.4 + 0.1 * np.abs(np.sin(1.7 * i))
+    t, y, s = [tt[:N0], tt[N0:]], [yy[:N0], yy[N0:]], [sg[:N0], sg[N0:]]
+    m = np.arange(5)
+    delays = np.stack([np.zeros(5), 1.0 * m], 1)
+    alpha = np.stack([1.0 + 0.1 * m, 1.5 - 0.1 * m], 1)
+    rho = 3.0 + 0.5 * m
+    ref, rinfo = oracle.loglik_batch("matern32", t, y, s, delays, alpha, rho, True)
+    got = np.array([float(ln[2]) for ln in lines if ln[0] == "loglik"])
+    ginfo = np.array([int(ln[3]) for ln in lines if ln[0] == "loglik"])
+    gprob = np.array([float(ln[4]) for ln in lines if ln[0] == "loglik"])
+    assert (rinfo == 0).all() and (ginfo == 0).all() and np.max(np.abs(got - ref) / np.abs(ref)) <= 1e-9
+    np.testing.assert_allclose(gprob, oracle.probabilities(ref), rtol=1e-6, atol=1e-300)
+    fits = [ln for ln in lines if ln[0] == "fit"]
+    assert len(fits) == 3
+    fl = np.array([float(f[2]) for f in fits])
+    fa = np.array([[float(f[3]), float(f[4])] for f in fits])
+    fr = np.array([float(f[5]) for f in fits])
+    assert all(int(f[6]) == 0 and 0 <= int(f[7]) <= 20 for f in fits)
+    fref, finfo = oracle.loglik_batch("matern32", t, y, s, np.array([[0.0, 0.0], [0.0, 2.0], [0.0, 4.0]]), fa, fr, True)
+    assert (finfo == 0).all() and np.max(np.abs(fl - fref) / np.abs(fref)) <= 1e-8     # value == objective at the optimum
+    stats = [ln for ln in lines if ln[0] == "stats"][0]
+    assert int(stats[1]) > 3 * 3 and int(stats[2]) < int(stats[1])
+    assert [ln for ln in lines if ln[0] == "badrho"][0][1:] == ["-2", "1"]
+    assert [ln for ln in lines if ln[0] == "nullcall"][0][1] == "-1"
