@@ -1,0 +1,66 @@
+// Host-only build of the optimiser of gpcc_grid_loglik (gpcc.jl_amd/csrc/gpcc_fit.h) for AddressSanitizer / UBSan on
+// the CPU (GPU sanitizers are not available on the pool).  Built and run by tests/test_host_cpu.py.
+#include "../../gpcc.jl_amd/csrc/gpcc_fit.h"
+
+#include <cstdio>
+
+static int rosen(void *, long K, const long *pidx, const double *X, double *f)
+{
+    for (long i = 0; i < K; ++i) {
+        const double x = X[2 * i], y = X[2 * i + 1];
+        f[i] = (pidx[i] % 7 == 3 && x < -1.0) ? std::numeric_limits<double>::quiet_NaN()   // a rejected region for some problems
+                                                : 100.0 * (y - x * x) * (y - x * x) + (1.0 - x) * (1.0 - x);
+    }
+    return 0;
+}
+
+static int bowl5(void *, long K, const long *, const double *X, double *f)
+{
+    for (long i = 0; i < K; ++i) {
+        double s = 0.0;
+        for (int d = 0; d < 5; ++d) s += (d + 1) * (X[5 * i + d] - 0.1 * d) * (X[5 * i + d] - 0.1 * d);
+        f[i] = s;
+    }
+    return 0;
+}
+
+int main()
+{
+    {
+        const long P = 257;
+        std::vector<double> x0(P * 2), xmin(P * 2), fmin(P);
+        gpccfit::Rng rg(5);
+        for (auto &v : x0) v = 4.0 * rg.uniform() - 2.0;
+        gpccfit::BatchedNelderMead nm(P, 2, 4000, 1e-10);
+        if (nm.run(rosen, nullptr, x0.data(), xmin.data(), fmin.data())) return 1;
+        long good = 0;
+        for (long p = 0; p < P; ++p) good += fmin[p] < 1e-6;
+        std::printf("rosenbrock: %ld of %ld converged, %lld evaluations in %lld rounds\n", good, P, nm.f_calls, nm.rounds);
+        if (good < P * 9 / 10) return 2;
+    }
+    {
+        const long P = 31;
+        std::vector<double> x0(P * 5, 1.0), xmin(P * 5), fmin(P);
+        gpccfit::BatchedNelderMead nm(P, 5, 3000, 1e-9);
+        if (nm.run(bowl5, nullptr, x0.data(), xmin.data(), fmin.data())) return 3;
+        for (long p = 0; p < P; ++p)
+            if (!(fmin[p] < 1e-6)) return 4;
+        std::printf("bowl5: ok\n");
+    }
+    {
+        double vary[3] = {1.0, 2.5, 0.3}, out[4 * 6 * 4];
+        gpccfit::initial_params(3, 4, 6, 0.1, 300.0, 42, vary, out);
+        for (double v : out)
+            if (!std::isfinite(v)) return 5;
+        for (int i = 0; i < 4 * 6; ++i) {
+            const double rho = gpccfit::transformbetween(out[i * 4 + 3], 0.1, 300.0);
+            if (!(rho > 0.1 && rho < 300.0)) return 6;
+            for (int l = 0; l < 3; ++l) {
+                const double a = gpccfit::makepositive(out[i * 4 + l]);
+                if (!(a > 0.79 * vary[l] && a < 1.21 * vary[l])) return 7;
+            }
+        }
+        std::printf("initial_params: ok\n");
+    }
+    return 0;
+}

@@ -73,3 +73,16 @@ def test_synthetic_recipe():
     assert ((gap <= 0.4 * 200 / 3) | (gap >= 0.6 * 200 / 3)).all()
     t2, y2, _, _ = synthetic.simulate_lightcurves([300, 200, 100], seed=4, gap_band=1)
     assert all(np.array_equal(a, b) for a, b in zip(t, t2)) and all(np.array_equal(a, b) for a, b in zip(y, y2))
+
+
+def test_native_optimiser_under_sanitizers(tmp_path):
+    """gpcc_fit.h (the C++ host logic of gpcc_grid_loglik) compiled host-only with AddressSanitizer + UBSan."""
+    import subprocess
+    exe = str(tmp_path / "fit_sanitize")
+    src = os.path.join(ROOT, "tests", "abi", "fit_host_sanitize.cpp")
+    cc = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", src, "-o", exe],
+                        capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr[-3000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr[-3000:]
+    assert "rosenbrock" in run.stdout and "bowl5: ok" in run.stdout and "initial_params: ok" in run.stdout
