@@ -776,3 +776,32 @@ def test_c_abi_from_plain_c(gp, oracle, tmp_path):
     assert int(stats[1]) > 3 * 3 and int(stats[2]) < int(stats[1])
     assert [ln for ln in lines if ln[0] == "badrho"][0][1:] == ["-2", "1"]
     assert [ln for ln in lines if ln[0] == "nullcall"][0][1] == "-1"
+
+
+def test_handle_lifetimes_leave_no_device_memory_behind(gp):
+    """create / use (every entry that allocates) / destroy, 24 times over, fp64 and fp32, including the native fit:
+    free device memory returns to where it was (hipMemGetInfo through torch)."""
+    import torch
+
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([300, 280], seed=1)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    M = 12
+    d = np.stack([np.zeros(M), np.linspace(0, 10, M)], 1)
+    free0 = None
+    for it in range(24):
+        with gp.Objective(t, y, s, "matern32", precision="fp32" if it % 2 else "fp64", slots_per_stream=16) as obj:
+            obj.loglik_batch(d, np.tile(alpha, (M, 1)), np.full(M, rho))
+            obj.loglik_batch(d[:3], np.tile(alpha, (3, 1)), np.full(3, rho))      # small group: spread map
+            if it % 4 == 0:
+                obj.predict([0.0, 2.0], alpha, rho, [np.linspace(0, 50, 40)] * 2)
+                obj.posterior_offsets([0.0, 2.0], alpha, rho)
+                obj.model_matrix([0.0, 2.0], alpha, rho)
+                obj.grid_loglik(d[:4], 3, rhomax=30.0)
+        gp.getprobabilities(np.zeros(10))
+        gp.delayedCovariance("OU", [1.0, 1.0], [0.0, 1.0], 2.0, [t[0][:10], t[1][:10]])
+        torch.cuda.synchronize()
+        free, _ = torch.cuda.mem_get_info()
+        if it == 3:
+            free0 = free
+    assert abs(free - free0) < 64 * 2**20, (free0, free)
