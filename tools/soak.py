@@ -14,6 +14,7 @@ import gpcc_amd as gp  # noqa: E402
 from oracle import oracle  # noqa: E402
 
 minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"     # python tools/soak.py 5 3 big: N ~ 1000-3000, groups up to 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 knames = ["OU", "rbf", "matern32", "matern52"]
 t_end = time.time() + 60 * minutes
@@ -26,6 +27,9 @@ while time.time() < t_end:
     lo = 2 if mb else 1
     big = rng.random() < 0.25
     Nl = [int(rng.integers(lo, 600 if big else 200)) if rng.random() < 0.8 else int(rng.integers(lo, 6)) for _ in range(L)]
+    if BIG:
+        L = int(rng.integers(1, 4))
+        Nl = [int(rng.integers(300, 1100)) for _ in range(L)]
     t = [rng.random(n) * rng.uniform(5, 80) for n in Nl]
     y = [rng.uniform(-5, 30) + rng.uniform(0.2, 3) * np.sin(0.2 * t[l] + l) + rng.standard_normal(Nl[l]) * 0.4 for l in range(L)]
     s = [rng.uniform(0.05, 1.0, n) for n in Nl]
@@ -34,14 +38,14 @@ while time.time() < t_end:
     # fp32: 1e-3 is the bar on the benchmark data (sigma = 0.75); here sigma goes down to 0.05 and alpha up to 5, and the
     # error of an fp32 factorisation grows with the condition number -- count the excursions, fail only beyond 5e-3
     tol = 5e-3 if prec == "fp32" else 1e-9
-    M = int(rng.choice([1, 2, 5, 7, 8, 9, 24, 25, 33, 70]))
+    M = int(rng.choice([1, 5, 40, 130, 300])) if BIG else int(rng.choice([1, 2, 5, 7, 8, 9, 24, 25, 33, 70]))
     delays = rng.uniform(-5, 20, (M, L))
     alpha = 10.0 ** rng.uniform(-0.7, 0.7, (M, L))
     rho = 10.0 ** rng.uniform(-0.5, 1.5, M)
     if M >= 25 and rng.random() < 0.5:
         delays[:, 0], alpha[:, 0], rho[:] = delays[0, 0], alpha[0, 0], rho[0]
-    ref, rinfo = oracle.loglik_batch(kname, t, y, s, delays, alpha, rho, mb, nthreads=16)
-    opts = dict(slots_per_stream=int(rng.choice([4, 16, 32, 64])), streams=int(rng.choice([1, 2])))
+    ref, rinfo = oracle.loglik_batch(kname, t, y, s, delays, alpha, rho, mb, nthreads=64 if BIG else 16)
+    opts = dict(slots_per_stream=int(rng.choice([64, 128, 256] if BIG else [4, 16, 32, 64])), streams=int(rng.choice([1, 2])))
     try:
         with gp.Objective(t, y, s, kname, marginalise_b=mb, precision=prec, **opts) as obj:
             obj.set_option("right_looking_max", int(rng.choice([0, 8, 24, 64])))
@@ -76,7 +80,7 @@ while time.time() < t_end:
     except Exception as ex:  # noqa: BLE001
         fails += 1
         print("FAIL trial %d: L=%d Nl=%s %s mb=%s %s M=%d opts=%s: %r" % (trials, L, Nl, kname, mb, prec, M, opts, ex), flush=True)
-    if trials % 25 == 0:
+    if trials % (2 if BIG else 25) == 0:
         print("trial %d, worst fp64 %.2e fp32 %.2e, failures %d" % (trials, worst["fp64"], worst["fp32"], fails), flush=True)
 print("soak finished: %d trials, %d failures, worst relative error fp64 %.3e fp32 %.3e; fp32 above 1e-3: %d of %d" %
       (trials, fails, worst["fp64"], worst["fp32"], over32, n32))
