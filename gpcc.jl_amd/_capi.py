@@ -26,6 +26,9 @@ SIGNATURES = {
     "gpcc_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, c_int_p, c_double_p, c_double_p,
                                    c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "gpcc_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "gpcc_create_multi": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, c_int_p, c_double_p, c_double_p,
+                                         c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_int_p, ctypes.c_int]),
+    "gpcc_multi_gathered": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_long_p, c_double_p, ctypes.c_long]),
     "gpcc_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_long]),
     "gpcc_get_option": (ctypes.c_long, [ctypes.c_void_p, ctypes.c_char_p]),
     "gpcc_get_constants": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, c_double_p]),
@@ -72,6 +75,45 @@ class GpccError(RuntimeError):
 
 
 _lib = None
+_preloaded = []
+
+
+def _share_torch_rocm_runtime():
+    """One HIP/HSA runtime per process.  libgpcc_hip.so asks the loader for `libamdhip64.so.7` / `librccl.so.1`
+    (DT_NEEDED = the SONAMEs, resolved to /opt/rocm/lib).  A torch ROCm wheel bundles its own copies under
+    torch/lib/ and asks for them by FILE name (`libamdhip64.so`, `librccl.so`, RPATH $ORIGIN).  glibc reuses an
+    already-loaded object when the requested name equals its SONAME or the path it was loaded from, so:
+      torch first, then libgpcc_hip   -> our `libamdhip64.so.7` matches the SONAME of torch's copy: ONE runtime;
+      libgpcc_hip first, then torch   -> `libamdhip64.so` matches nothing loaded: torch maps its own copy beside
+                                         /opt/rocm's, two HSA runtimes open the GPU and the second finds none
+                                         ("No HIP GPUs are available", round-1 gpurun_out/test12.log).
+    Whenever a torch installation with bundled ROCm libraries exists, map THOSE first (by path): our
+    SONAME requests bind to them now, and torch's later file-name requests resolve to the same paths.  Either import
+    order then shares one runtime.  Without torch (a Julia or C host) the system libraries are used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libamdhip64.so", "librccl.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            _preloaded.append(ctypes.CDLL(path))   # RTLD_LOCAL: a global-scope librccl ahead of torch ends in a double free at exit
+
+
+def loaded_rocm_libraries():
+    """Paths of every libamdhip64 / libhsa-runtime64 / librccl mapped into this process (from /proc/self/maps)."""
+    seen = []
+    with open("/proc/self/maps") as f:
+        for line in f:
+            path = line.rsplit(" ", 1)[-1].strip()
+            base = os.path.basename(path)
+            if base.startswith(("libamdhip64", "libhsa-runtime64", "librccl")) and path not in seen:
+                seen.append(path)
+    return seen
 
 
 def load():
@@ -81,12 +123,7 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950).  gpcc_amd has no CPU fallback." % LIB_PATH)
-        if "torch" in sys.modules:
-            # torch wheels bundle their own HIP runtime; when both live in one process torch must
-            # initialise the GPU first (the other order has been seen to end in "No HIP GPUs are available")
-            import torch
-            if torch.cuda.is_available():
-                torch.cuda.init()
+        _share_torch_rocm_runtime()
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the library does not export the symbol

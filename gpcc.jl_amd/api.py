@@ -137,11 +137,12 @@ def mvnormal_logpdf(mu, Sigma, x, device=0):
 
 class Objective:
     """The marginal log-likelihood objective(alpha, rho) of gpccfixdelay, bound to one data set and
-    living on one GPU.  The delay vector is an argument (the reference captures tau in the
-    closure; a grid sweep varies it), so one handle serves a whole delay grid."""
+    living on one GPU -- or, with devices=[...], replicated on several GPUs of this process (gpcc_create_multi:
+    batches are sharded in contiguous blocks, one all-gather collects them).  The delay vector is an argument
+    (the reference captures tau in the closure; a grid sweep varies it), so one handle serves a whole delay grid."""
 
     def __init__(self, tarray, yarray, stdarray, kernel, marginalise_b=True, precision="fp64", device=0,
-                 streams=None, slots_per_stream=None):
+                 streams=None, slots_per_stream=None, devices=None):
         self._h = None
         self.kernel = _kernel(kernel)
         L = len(tarray)
@@ -155,8 +156,14 @@ class Objective:
         self.device = int(device)
         lib = _capi.load()
         h = ctypes.c_void_p()
-        _capi.check(lib.gpcc_create(ctypes.byref(h), L, _ip(Nl), _dp(t), _dp(y), _dp(s), self.kernel.id,
-                                    int(self.marginalise_b), _capi.PRECISION_IDS[precision], self.device))
+        if devices is None:
+            _capi.check(lib.gpcc_create(ctypes.byref(h), L, _ip(Nl), _dp(t), _dp(y), _dp(s), self.kernel.id,
+                                        int(self.marginalise_b), _capi.PRECISION_IDS[precision], self.device))
+        else:
+            devs = np.ascontiguousarray(devices, dtype=np.int32)
+            self.device = int(devs[0]) if len(devs) else 0
+            _capi.check(lib.gpcc_create_multi(ctypes.byref(h), L, _ip(Nl), _dp(t), _dp(y), _dp(s), self.kernel.id,
+                                              int(self.marginalise_b), _capi.PRECISION_IDS[precision], _ip(devs), len(devs)))
         self._h = h
         for key, val in (("streams", streams), ("slots_per_stream", slots_per_stream)):
             if val is not None:
@@ -195,6 +202,17 @@ class Objective:
         mu, sb, r = np.empty(self.L), np.empty(self.L), np.empty(self.N)
         self._chk(_capi.load().gpcc_get_constants(self._h, _dp(mu), _dp(sb), _dp(r)))
         return mu, sb, r
+
+    def gathered(self, which=0):
+        """Multi-device handles: the all-gathered [loglik | info] blocks of the last loglik_batch as they sit on
+        device `which` -> (loglik[n_devices, blk], info[n_devices, blk]) (padding: NaN / 0)."""
+        blk = ctypes.c_long(0)
+        self._chk(_capi.load().gpcc_multi_gathered(self._h, int(which), ctypes.byref(blk), None, 0))
+        n = self.get_option("n_devices")
+        buf = np.empty(2 * blk.value * n, dtype=np.float64)
+        self._chk(_capi.load().gpcc_multi_gathered(self._h, int(which), ctypes.byref(blk), _dp(buf), buf.size))
+        buf = buf.reshape(n, 2, blk.value)
+        return buf[:, 0, :], buf[:, 1, :].astype(np.int32)
 
     # -- the hot path ---------------------------------------------------------------------------
     def _params(self, delays, alpha, rho):

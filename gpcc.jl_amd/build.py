@@ -26,7 +26,7 @@ def build(force=False, verbose=False):
         hipcc = "hipcc"
     tmp = "%s.tmp%d" % (LIB_PATH, os.getpid())      # link elsewhere, then rename: no reader ever sees a partial file
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           "-o", tmp, os.path.join(CSRC, "gpcc_hip.hip")]
+           "-o", tmp, os.path.join(CSRC, "gpcc_hip.hip"), "-L/opt/rocm/lib", "-lrccl", "-pthread"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode:
         print(" ".join(cmd))

@@ -5,11 +5,15 @@
 
 #include "../../include/gpcc_hip.h"
 
+#include <rccl/rccl.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <string>
+#include <thread>
 #include <vector>
 
 #define GPCC_VERSION_NUMBER 100
@@ -56,7 +60,21 @@ struct gpcc_handle_s {
     long prof_n[GPCC_PROF_COUNT] = {};
     double prof_ms[GPCC_PROF_COUNT] = {};
     std::string err;
+    // multi-device flavour (gpcc_create_multi): this handle owns one single-device handle per entry of device_ids and
+    // nothing else on a device; batches are cut into contiguous blocks, one worker thread per device, and the results
+    // are collected with ONE all-gather (RCCL over xGMI; through host memory when device ids repeat)
+    std::vector<gpcc_handle_t> subs;
+    std::vector<ncclComm_t> comms;        // one per sub-handle when the gather is RCCL's
+    std::vector<double *> d_send, d_recv; // per sub: [loglik(blk) | info(blk)] and n x that
+    std::vector<double> h_gather;
+    long gather_cap = 0;                  // evaluations per device the gather buffers hold
+    long gather_blk = 0;                  // block length of the last gathered batch
+    int gather_mode = 0;                  // GPCC_GATHER_*
+    bool is_multi() const { return !subs.empty(); }
 };
+
+// the handle that holds the light curves and answers the single-matrix utilities (prediction, postb, dense exports)
+static inline gpcc_handle_t primary(gpcc_handle_t h) { return (h && h->is_multi()) ? h->subs[0] : h; }
 
 static int fail(gpcc_handle_t h, int code, const char *fmt, ...)
 {
@@ -82,15 +100,51 @@ extern "C" int gpcc_version(void) { return GPCC_VERSION_NUMBER; }
 
 extern "C" const char *gpcc_last_error(gpcc_handle_t h) { return h ? h->err.c_str() : g_err.c_str(); }
 
-static int set_device(gpcc_handle_t h, int device)
+// Every extern "C" entry that touches the GPU runs under a DeviceGuard: the calling thread's current device is
+// switched to the handle's for the duration of the call and restored on return, so a host framework (Julia's
+// AMDGPU.jl, torch) whose current device differs never finds its later allocations on another GPU.
+struct DeviceGuard {
+    int prev = -1, rc = 0;
+    DeviceGuard(gpcc_handle_t h, int device)
+    {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0) {
+            rc = fail(h, GPCC_ERR_HIP, "no HIP device available (%s); libgpcc_hip has no CPU fallback",
+                      e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+            return;
+        }
+        if (device < 0 || device >= n) {
+            rc = fail(h, GPCC_ERR_ARGUMENT, "device_id %d out of range [0,%d)", device, n);
+            return;
+        }
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        e = hipSetDevice(device);
+        if (e != hipSuccess) rc = fail(h, GPCC_ERR_HIP, "hipSetDevice(%d) failed: %s", device, hipGetErrorString(e));
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define GPCC_ON_DEVICE(h, device)      \
+    DeviceGuard guard_((h), (device)); \
+    if (guard_.rc) return guard_.rc
+
+static int multi_destroy(gpcc_handle_t h);
+static int multi_loglik_batch(gpcc_handle_t h, int M, const double *delays, const double *alpha, const double *rho,
+                              double *loglik, int *info);
+
+// a caller-supplied stream must live on the device the kernels are launched on (NULL = that device's default stream)
+static int stream_on_device(gpcc_handle_t h, void *stream, int device)
 {
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0)
-        return fail(h, GPCC_ERR_HIP, "no HIP device available (%s); libgpcc_hip has no CPU fallback",
-                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
-    if (device < 0 || device >= n) return fail(h, GPCC_ERR_ARGUMENT, "device_id %d out of range [0,%d)", device, n);
-    HIPCHK(h, hipSetDevice(device));
+    if (!stream) return 0;
+    hipDevice_t sd = -1;
+    hipError_t e = hipStreamGetDevice((hipStream_t)stream, &sd);
+    if (e != hipSuccess) return fail(h, GPCC_ERR_ARGUMENT, "stream argument is not a valid hipStream_t (%s)", hipGetErrorString(e));
+    if ((int)sd != device) return fail(h, GPCC_ERR_ARGUMENT, "stream belongs to device %d, the handle to device %d", (int)sd, device);
     return 0;
 }
 
@@ -113,8 +167,7 @@ extern "C" int gpcc_create(gpcc_handle_t *out, int L, const int *Nl, const doubl
         N += Nl[l];
     }
     if (N > 65536) return fail(nullptr, GPCC_ERR_ARGUMENT, "N=%ld too large", N);
-    int rc = set_device(nullptr, device_id);
-    if (rc) return rc;
+    GPCC_ON_DEVICE(nullptr, device_id);
 
     gpcc_handle_t h = new gpcc_handle_s();
     h->device = device_id;
@@ -204,7 +257,8 @@ static void free_workspace(gpcc_handle_t h)
 extern "C" int gpcc_destroy(gpcc_handle_t h)
 {
     if (!h) return 0;
-    hipSetDevice(h->device);
+    if (h->is_multi()) return multi_destroy(h);
+    DeviceGuard guard_(nullptr, h->device);   // restores the caller's current device
     hipDeviceSynchronize();
     for (auto &r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     free_workspace(h);
@@ -219,6 +273,13 @@ extern "C" int gpcc_destroy(gpcc_handle_t h)
 extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
 {
     if (!h || !key) return fail(h, GPCC_ERR_ARGUMENT, "NULL handle/key");
+    if (h->is_multi()) {   // every device gets the same tunables
+        for (gpcc_handle_t sub : h->subs) {
+            const int rc = gpcc_set_option(sub, key, v);
+            if (rc) return fail(h, rc, "%s", sub->err.c_str());
+        }
+        return 0;
+    }
     if (!strcmp(key, "streams")) {
         if (v < 1 || v > GPCC_MAX_STREAMS) return fail(h, GPCC_ERR_ARGUMENT, "streams must be in [1,%d]", GPCC_MAX_STREAMS);
         h->streams = (int)v;
@@ -239,6 +300,9 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
 extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
 {
     if (!h || !key) return -1;
+    if (!strcmp(key, "n_devices")) return h->is_multi() ? (long)h->subs.size() : 1;
+    if (!strcmp(key, "gather_mode")) return h->gather_mode;
+    h = primary(h);
     if (!strcmp(key, "streams")) return h->streams;
     if (!strcmp(key, "slots_per_stream")) return h->slots_per_stream;
     if (!strcmp(key, "right_looking_max")) return h->right_looking_max;
@@ -254,6 +318,7 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
 extern "C" int gpcc_get_constants(gpcc_handle_t h, double *mean_b, double *Sigma_b, double *resid)
 {
     if (!h) return fail(h, GPCC_ERR_ARGUMENT, "NULL handle");
+    h = primary(h);
     if (mean_b) memcpy(mean_b, h->mean_b, sizeof(double) * h->L);
     if (Sigma_b) memcpy(Sigma_b, h->sigma_b, sizeof(double) * h->L);
     if (resid) memcpy(resid, h->resid_host.data(), sizeof(double) * h->N);
@@ -412,7 +477,9 @@ extern "C" int gpcc_loglik_batch_device(gpcc_handle_t h, int M, const double *d_
     if (M < 0) return fail(h, GPCC_ERR_ARGUMENT, "M=%d < 0", M);
     if (M == 0) return 0;
     if (!d_delays || !d_alpha || !d_rho || !d_loglik || !d_info) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
-    int rc = set_device(h, h->device);
+    if (h->is_multi()) return fail(h, GPCC_ERR_UNSUPPORTED, "a multi-device handle takes host pointers (gpcc_loglik_batch): device pointers belong to one device");
+    GPCC_ON_DEVICE(h, h->device);
+    int rc = stream_on_device(h, stream, h->device);
     if (rc) return rc;
     rc = ensure_workspace(h);
     if (rc) return rc;
@@ -460,16 +527,12 @@ static int ensure_staging(gpcc_handle_t h, long M)
     return 0;
 }
 
-extern "C" int gpcc_loglik_batch(gpcc_handle_t h, int M, const double *delays, const double *alpha,
-                                 const double *rho, double *loglik, int *info)
+// Host-pointer parameters of M evaluations -> the handle's staging buffers -> the device path, results left in
+// d_loglik / d_info (device), everything ordered on h->main_stream, nothing synchronised.  The caller holds the device.
+static int enqueue_host_batch(gpcc_handle_t h, int M, const double *delays, const double *alpha, const double *rho,
+                              double *d_loglik, int *d_info)
 {
-    if (!h) return fail(h, GPCC_ERR_ARGUMENT, "NULL handle");
-    if (M < 0) return fail(h, GPCC_ERR_ARGUMENT, "M=%d < 0", M);
-    if (M == 0) return 0;
-    if (!delays || !alpha || !rho || !loglik || !info) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
-    int rc = set_device(h, h->device);
-    if (rc) return rc;
-    rc = ensure_staging(h, M);
+    int rc = ensure_staging(h, M);
     if (rc) return rc;
     const long ML = (long)M * h->L;
     double *dd = h->d_par, *da = h->d_par + ML, *dr = h->d_par + 2 * ML;
@@ -486,8 +549,21 @@ extern "C" int gpcc_loglik_batch(gpcc_handle_t h, int M, const double *delays, c
         }
         h->share_now = same;
     }
-    rc = gpcc_loglik_batch_device(h, M, dd, da, dr, h->d_out, h->d_oinfo, h->main_stream);
+    rc = gpcc_loglik_batch_device(h, M, dd, da, dr, d_loglik ? d_loglik : h->d_out, d_info ? d_info : h->d_oinfo, h->main_stream);
     h->share_now = false;
+    return rc;
+}
+
+extern "C" int gpcc_loglik_batch(gpcc_handle_t h, int M, const double *delays, const double *alpha,
+                                 const double *rho, double *loglik, int *info)
+{
+    if (!h) return fail(h, GPCC_ERR_ARGUMENT, "NULL handle");
+    if (M < 0) return fail(h, GPCC_ERR_ARGUMENT, "M=%d < 0", M);
+    if (M == 0) return 0;
+    if (!delays || !alpha || !rho || !loglik || !info) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
+    if (h->is_multi()) return multi_loglik_batch(h, M, delays, alpha, rho, loglik, info);
+    GPCC_ON_DEVICE(h, h->device);
+    int rc = enqueue_host_batch(h, M, delays, alpha, rho, nullptr, nullptr);
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(loglik, h->d_out, sizeof(double) * M, hipMemcpyDeviceToHost, h->main_stream));
     HIPCHK(h, hipMemcpyAsync(info, h->d_oinfo, sizeof(int) * M, hipMemcpyDeviceToHost, h->main_stream));
@@ -517,8 +593,8 @@ struct AugRun {
 static int run_augmented(gpcc_handle_t h, const double *delays, const double *alpha, double rho, int next,
                          const double *ext_t, const int *ext_band, int marginalise_b, AugRun &a, bool factor = true)
 {
-    int rc = set_device(h, h->device);
-    if (rc) return rc;
+    GPCC_ON_DEVICE(h, h->device);
+    int rc = 0;
     rc = set_kernel_attributes(h);
     if (rc) return rc;
     rc = ensure_staging(h, 1);
@@ -607,6 +683,7 @@ static int fetch_augmented(gpcc_handle_t h, AugRun &a, double *block, double *ze
 extern "C" int gpcc_model_matrix(gpcc_handle_t h, const double *delays, const double *alpha, double rho, double *K_out)
 {
     if (!h || !delays || !alpha || !K_out) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
+    h = primary(h);
     AugRun a;
     int rc = run_augmented(h, delays, alpha, rho, 0, nullptr, nullptr, h->mb, a, false);
     if (rc) return rc;
@@ -618,6 +695,7 @@ extern "C" int gpcc_factor_dense(gpcc_handle_t h, const double *delays, const do
                                  double *L_out, int *info)
 {
     if (!h || !delays || !alpha || !L_out) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
+    h = primary(h);
     AugRun a;
     int rc = run_augmented(h, delays, alpha, rho, 0, nullptr, nullptr, h->mb, a, true);
     if (rc) return rc;
@@ -629,6 +707,7 @@ extern "C" int gpcc_predict(gpcc_handle_t h, const double *delays, const double 
                             const double *ttest, double *mu_out, double *Sigma_out, double *loglik, int *info)
 {
     if (!h || !delays || !alpha || !Ntest || !ttest || !mu_out || !Sigma_out) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
+    h = primary(h);
     long nt = 0;
     for (int l = 0; l < h->L; ++l) { if (Ntest[l] < 0) return fail(h, GPCC_ERR_ARGUMENT, "negative Ntest"); nt += Ntest[l]; }
     if (nt <= 0 || nt > 32768) return fail(h, GPCC_ERR_ARGUMENT, "total number of test points %ld outside [1, 32768]", nt);
@@ -651,6 +730,7 @@ extern "C" int gpcc_posterior_offsets(gpcc_handle_t h, const double *delays, con
                                       double *mu_postb, double *Sigma_postb, int *info)
 {
     if (!h || !delays || !alpha || !mu_postb || !Sigma_postb) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
+    h = primary(h);
     if (!h->mb) return fail(h, GPCC_ERR_ARGUMENT, "the fixed-b variant (gpccfixdelay.jl) has no posterior over offsets");
     const int L = h->L, ne = L + 1;
     std::vector<int> eb(ne);
@@ -695,8 +775,8 @@ extern "C" int gpcc_mvnormal_logpdf(int n, const double *Sigma, const double *mu
                                     int *info, int device_id)
 {
     if (n < 1 || n > 65536 || !Sigma || !x || !loglik || !info) return fail(nullptr, GPCC_ERR_ARGUMENT, "bad argument");
-    int rc = set_device(nullptr, device_id);
-    if (rc) return rc;
+    GPCC_ON_DEVICE(nullptr, device_id);
+    int rc = 0;
     gpcc_handle_s tmp;   // stack handle: only err/prof fields are touched by the helpers
     rc = set_kernel_attributes(&tmp);
     if (rc) return fail(nullptr, rc, "%s", tmp.err.c_str());
@@ -745,8 +825,8 @@ extern "C" int gpcc_covariance(int kernel_id, int L, const double *scale, const 
     for (int l = 0; l < L; ++l)
         if (!(scale[l] > 0.0)) return fail(nullptr, GPCC_ERR_ARGUMENT, "AssertionError: all(scale .> 0)");
     if (rho <= 0.0) return fail(nullptr, GPCC_ERR_ARGUMENT, "ρ=%.8f is <= 0", rho);
-    int rc = set_device(nullptr, device_id);
-    if (rc) return rc;
+    GPCC_ON_DEVICE(nullptr, device_id);
+    int rc = 0;
     long nx = 0, ny = 0;
     for (int l = 0; l < L; ++l) {
         if (Nx[l] < 0 || Ny[l] < 0) return fail(nullptr, GPCC_ERR_ARGUMENT, "negative band length");
@@ -787,6 +867,15 @@ extern "C" int gpcc_probabilities_device(int G, const double *d_loglik, const do
                                          void *stream)
 {
     if (G <= 0 || !d_loglik || !d_out) return fail(nullptr, GPCC_ERR_ARGUMENT, "bad argument");
+    int dev = -1;
+    if (stream) {   // the launch goes to the stream's device whatever the thread's current device is
+        hipDevice_t sd = -1;
+        if (hipStreamGetDevice((hipStream_t)stream, &sd) != hipSuccess) return fail(nullptr, GPCC_ERR_ARGUMENT, "stream argument is not a valid hipStream_t");
+        dev = (int)sd;
+    } else if (hipGetDevice(&dev) != hipSuccess) {
+        return fail(nullptr, GPCC_ERR_HIP, "no HIP device available; libgpcc_hip has no CPU fallback");
+    }
+    GPCC_ON_DEVICE(nullptr, dev);
     gpcc_probabilities_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(G, d_loglik, d_logprior, d_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, GPCC_ERR_HIP, "gpcc_probabilities: %s", hipGetErrorString(e));
@@ -796,8 +885,8 @@ extern "C" int gpcc_probabilities_device(int G, const double *d_loglik, const do
 extern "C" int gpcc_probabilities(int G, const double *loglik, const double *logprior, double *out, int device_id)
 {
     if (G <= 0 || !loglik || !out) return fail(nullptr, GPCC_ERR_ARGUMENT, "bad argument");
-    int rc = set_device(nullptr, device_id);
-    if (rc) return rc;
+    GPCC_ON_DEVICE(nullptr, device_id);
+    int rc = 0;
     double *d = nullptr;
     hipError_t e = hipMalloc(&d, sizeof(double) * 3 * (size_t)G);
     if (e == hipSuccess) e = hipMemcpy(d, loglik, sizeof(double) * G, hipMemcpyHostToDevice);
@@ -849,6 +938,7 @@ extern "C" int gpcc_initial_params(gpcc_handle_t h, int numberofrestarts, int in
         return fail(h, GPCC_ERR_ARGUMENT, "bad fit options (restarts %d, initialrandom %d, rho in (%g, %g))",
                     numberofrestarts, initialrandom, rhomin, rhomax);
     double vary[GPCC_MAXL];
+    h = primary(h);
     band_variances(h, vary);
     gpccfit::initial_params(h->L, numberofrestarts, initialrandom, rhomin, rhomax, seed, vary, out);
     return 0;
@@ -910,7 +1000,7 @@ extern "C" int gpcc_grid_loglik(gpcc_handle_t h, int G, const double *delays, in
     if (G < 0) return fail(h, GPCC_ERR_ARGUMENT, "G=%d < 0", G);
     if (G == 0) return 0;
     if (!delays || !loglik_out || !alpha_out || !rho_out || !info_out) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
-    const int L = h->L, R = numberofrestarts, C = initialrandom, n = L + 1;
+    const int L = primary(h)->L, R = numberofrestarts, C = initialrandom, n = L + 1;
     if (R < 1 || C < 1 || iterations < 0 || !(rhomin > 0.0) || !(rhomax > rhomin + 2e-3))
         return fail(h, GPCC_ERR_ARGUMENT, "bad fit options (iterations %d, restarts %d, initialrandom %d, rho in (%g, %g))",
                     iterations, R, C, rhomin, rhomax);
@@ -920,7 +1010,7 @@ extern "C" int gpcc_grid_loglik(gpcc_handle_t h, int G, const double *delays, in
     if (init_params) memcpy(cands.data(), init_params, sizeof(double) * cands.size());
     else {
         double vary[GPCC_MAXL];
-        band_variances(h, vary);
+        band_variances(primary(h), vary);
         gpccfit::initial_params(L, R, C, rhomin, rhomax, seed, vary, cands.data());
     }
     FitEval ev{h, delays, R, L, rhomin, rhomax, {}, {}, {}, {}, {}};
@@ -963,10 +1053,206 @@ extern "C" int gpcc_grid_loglik(gpcc_handle_t h, int G, const double *delays, in
 }
 
 // ------------------------------------------------------------------------------------------
+// Multi-device handles: the delay grid shards over the devices of ONE process -- the shape that fits
+// a Julia host (README.md:181-211, :258-287 parallelise the same map with pmap workers).  Static contiguous block
+// partition of every batch, light curves replicated at create, no data-path collective, and ONE all-gather of
+// [loglik | info] per call (RCCL over xGMI: ncclCommInitAll + ncclAllGather inside a group), after which every device
+// holds the whole vector.  RCCL refuses a communicator with a repeated device, so device lists with duplicates (the
+// one-GPU rehearsal {0, 0}) and single-device lists gather through host memory instead (gather_mode says which).
+// ------------------------------------------------------------------------------------------
+__global__ void gpcc_pack_gather(int cnt, long blk, const int *info, double *send)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= blk) return;
+    if (i >= cnt) send[i] = __builtin_nan("");                 // padding of the last block
+    send[blk + i] = (i < cnt) ? (double)info[i] : 0.0;         // info travels as a double: one collective, one dtype
+}
+
+static int multi_fail(gpcc_handle_t h, gpcc_handle_t sub, int rc)
+{
+    return fail(h, rc, "device %d: %s", sub->device, sub->err.c_str());
+}
+
+static void multi_free_buffers(gpcc_handle_t h)
+{
+    for (size_t i = 0; i < h->subs.size(); ++i) {
+        DeviceGuard g(nullptr, h->subs[i]->device);
+        if (i < h->d_send.size()) hipFree(h->d_send[i]);
+        if (i < h->d_recv.size()) hipFree(h->d_recv[i]);
+    }
+    h->d_send.clear();
+    h->d_recv.clear();
+    h->gather_cap = 0;
+}
+
+static int multi_ensure_buffers(gpcc_handle_t h, long blk)
+{
+    if (blk <= h->gather_cap) return 0;
+    multi_free_buffers(h);
+    const size_t n = h->subs.size();
+    h->d_send.assign(n, nullptr);
+    h->d_recv.assign(n, nullptr);
+    for (size_t i = 0; i < n; ++i) {
+        GPCC_ON_DEVICE(h, h->subs[i]->device);
+        HIPCHK(h, hipMalloc(&h->d_send[i], sizeof(double) * 2 * blk));
+        HIPCHK(h, hipMalloc(&h->d_recv[i], sizeof(double) * 2 * blk * n));
+    }
+    h->h_gather.resize((size_t)2 * blk * n);
+    h->gather_cap = blk;
+    return 0;
+}
+
+static int multi_destroy(gpcc_handle_t h)
+{
+    for (size_t i = 0; i < h->comms.size(); ++i) {
+        DeviceGuard g(nullptr, h->subs[i]->device);
+        ncclCommDestroy(h->comms[i]);
+    }
+    multi_free_buffers(h);
+    for (gpcc_handle_t sub : h->subs) gpcc_destroy(sub);
+    delete h;
+    return 0;
+}
+
+extern "C" int gpcc_create_multi(gpcc_handle_t *out, int L, const int *Nl, const double *t, const double *y,
+                                 const double *sigma, int kernel_id, int marginalise_b, int precision,
+                                 const int *device_ids, int n_devices)
+{
+    if (!out) return fail(nullptr, GPCC_ERR_ARGUMENT, "handle pointer is NULL");
+    *out = nullptr;
+    if (!device_ids || n_devices < 1 || n_devices > 64)
+        return fail(nullptr, GPCC_ERR_ARGUMENT, "device_ids is NULL or n_devices=%d outside [1,64]", n_devices);
+    gpcc_handle_t h = new gpcc_handle_s();
+    bool distinct = true;
+    for (int i = 0; i < n_devices; ++i)
+        for (int j = 0; j < i; ++j) distinct = distinct && device_ids[i] != device_ids[j];
+    for (int i = 0; i < n_devices; ++i) {
+        gpcc_handle_t sub = nullptr;
+        const int rc = gpcc_create(&sub, L, Nl, t, y, sigma, kernel_id, marginalise_b, precision, device_ids[i]);
+        if (rc) {   // g_err holds gpcc_create's message
+            const std::string msg = g_err;
+            multi_destroy(h);
+            return fail(nullptr, rc, "device_ids[%d] = %d: %s", i, device_ids[i], msg.c_str());
+        }
+        h->subs.push_back(sub);
+    }
+    h->device = device_ids[0];
+    h->gather_mode = GPCC_GATHER_HOST;
+    if (distinct && n_devices > 1) {
+        h->comms.assign(n_devices, nullptr);
+        const ncclResult_t r = ncclCommInitAll(h->comms.data(), n_devices, device_ids);
+        if (r != ncclSuccess) {
+            h->comms.clear();
+            multi_destroy(h);
+            return fail(nullptr, GPCC_ERR_HIP, "ncclCommInitAll over %d devices failed: %s", n_devices, ncclGetErrorString(r));
+        }
+        h->gather_mode = GPCC_GATHER_RCCL;
+    }
+    *out = h;
+    return 0;
+}
+
+// one device's share of a batch: evaluations [lo, lo + cnt) -> d_send[i] = [loglik(blk) | info(blk)], stream-ordered
+static int multi_worker(gpcc_handle_t h, int i, long blk, long lo, int cnt, const double *delays, const double *alpha,
+                        const double *rho)
+{
+    gpcc_handle_t sub = h->subs[i];
+    GPCC_ON_DEVICE(sub, sub->device);
+    int rc = ensure_staging(sub, cnt > 0 ? cnt : 1);
+    if (rc) return rc;
+    if (cnt > 0) {
+        rc = enqueue_host_batch(sub, cnt, delays + lo * sub->L, alpha + lo * sub->L, rho + lo, h->d_send[i], sub->d_oinfo);
+        if (rc) return rc;
+    }
+    gpcc_pack_gather<<<(unsigned)((blk + 255) / 256), 256, 0, sub->main_stream>>>(cnt, blk, sub->d_oinfo, h->d_send[i]);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(sub, GPCC_ERR_HIP, "gpcc_pack_gather: %s", hipGetErrorString(e));
+    if (h->gather_mode == GPCC_GATHER_HOST) {   // this device's block -> its place in the host gather buffer
+        HIPCHK(sub, hipMemcpyAsync(h->h_gather.data() + (size_t)i * 2 * blk, h->d_send[i], sizeof(double) * 2 * blk,
+                                   hipMemcpyDeviceToHost, sub->main_stream));
+        HIPCHK(sub, hipStreamSynchronize(sub->main_stream));
+    }
+    return 0;
+}
+
+static int multi_loglik_batch(gpcc_handle_t h, int M, const double *delays, const double *alpha, const double *rho,
+                              double *loglik, int *info)
+{
+    const int n = (int)h->subs.size();
+    const long blk = ((long)M + n - 1) / n;
+    int rc = multi_ensure_buffers(h, blk);
+    if (rc) return rc;
+    std::vector<int> rcs(n, 0);
+    {
+        std::vector<std::thread> workers;
+        for (int i = 0; i < n; ++i) {
+            const long lo = (long)i * blk;
+            const int cnt = (int)std::max(0L, std::min(blk, (long)M - lo));
+            workers.emplace_back([=, &rcs] { rcs[i] = multi_worker(h, i, blk, lo, cnt, delays, alpha, rho); });
+        }
+        for (auto &w : workers) w.join();
+    }
+    for (int i = 0; i < n; ++i)
+        if (rcs[i]) return multi_fail(h, h->subs[i], rcs[i]);
+    h->gather_blk = blk;
+    const size_t nb = sizeof(double) * 2 * blk;
+    if (h->gather_mode == GPCC_GATHER_RCCL) {
+        // THE collective of the path: every device contributes its block and receives all of them
+        ncclResult_t r = ncclGroupStart();
+        for (int i = 0; i < n && r == ncclSuccess; ++i)
+            r = ncclAllGather(h->d_send[i], h->d_recv[i], (size_t)2 * blk, ncclDouble, h->comms[i], h->subs[i]->main_stream);
+        const ncclResult_t r2 = ncclGroupEnd();
+        if (r == ncclSuccess) r = r2;
+        if (r != ncclSuccess) return fail(h, GPCC_ERR_HIP, "ncclAllGather failed: %s", ncclGetErrorString(r));
+        for (int i = 0; i < n; ++i) {
+            GPCC_ON_DEVICE(h, h->subs[i]->device);
+            HIPCHK(h, hipStreamSynchronize(h->subs[i]->main_stream));
+        }
+        GPCC_ON_DEVICE(h, h->subs[0]->device);
+        HIPCHK(h, hipMemcpy(h->h_gather.data(), h->d_recv[0], nb * n, hipMemcpyDeviceToHost));
+    } else {
+        // same result through host memory: the blocks are already in h_gather; every device gets the whole vector
+        for (int i = 0; i < n; ++i) {
+            GPCC_ON_DEVICE(h, h->subs[i]->device);
+            HIPCHK(h, hipMemcpyAsync(h->d_recv[i], h->h_gather.data(), nb * n, hipMemcpyHostToDevice, h->subs[i]->main_stream));
+        }
+        for (int i = 0; i < n; ++i) {
+            GPCC_ON_DEVICE(h, h->subs[i]->device);
+            HIPCHK(h, hipStreamSynchronize(h->subs[i]->main_stream));
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        const long lo = (long)i * blk;
+        const long cnt = std::max(0L, std::min(blk, (long)M - lo));
+        const double *src = h->h_gather.data() + (size_t)i * 2 * blk;
+        for (long j = 0; j < cnt; ++j) {
+            loglik[lo + j] = src[j];
+            info[lo + j] = (int)src[blk + j];
+        }
+    }
+    return 0;
+}
+
+// the gathered vector as it sits on device `which` of the handle after the last gpcc_loglik_batch (tests; a host that
+// wants getprobabilities on a device of its choice): [loglik(blk) | info(blk)] per device block, n blocks
+extern "C" int gpcc_multi_gathered(gpcc_handle_t h, int which, long *blk_out, double *out, long capacity)
+{
+    if (!h || !h->is_multi()) return fail(h, GPCC_ERR_ARGUMENT, "not a multi-device handle");
+    if (which < 0 || which >= (int)h->subs.size()) return fail(h, GPCC_ERR_ARGUMENT, "device index %d outside [0,%d)", which, (int)h->subs.size());
+    const long total = 2 * h->gather_blk * (long)h->subs.size();
+    if (blk_out) *blk_out = h->gather_blk;
+    if (!out) return 0;
+    if (capacity < total) return fail(h, GPCC_ERR_ARGUMENT, "capacity %ld < %ld", capacity, total);
+    GPCC_ON_DEVICE(h, h->subs[which]->device);
+    HIPCHK(h, hipMemcpy(out, h->d_recv[which], sizeof(double) * total, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 static void prof_collect(gpcc_handle_t h)
 {
     if (h->recs.empty()) return;
-    hipSetDevice(h->device);
+    DeviceGuard guard_(nullptr, h->device);
     hipDeviceSynchronize();
     for (auto &r : h->recs) {
         float ms = 0.f;
@@ -980,6 +1266,7 @@ static void prof_collect(gpcc_handle_t h)
 extern "C" int gpcc_profile_enable(gpcc_handle_t h, int on)
 {
     if (!h) return fail(h, GPCC_ERR_ARGUMENT, "NULL handle");
+    h = primary(h);
     prof_collect(h);
     h->prof = on != 0;
     return 0;
@@ -988,6 +1275,7 @@ extern "C" int gpcc_profile_enable(gpcc_handle_t h, int on)
 extern "C" int gpcc_profile_reset(gpcc_handle_t h)
 {
     if (!h) return fail(h, GPCC_ERR_ARGUMENT, "NULL handle");
+    h = primary(h);
     prof_collect(h);
     for (int i = 0; i < GPCC_PROF_COUNT; ++i) { h->prof_n[i] = 0; h->prof_ms[i] = 0.0; }
     return 0;
@@ -996,6 +1284,7 @@ extern "C" int gpcc_profile_reset(gpcc_handle_t h)
 extern "C" int gpcc_profile_get(gpcc_handle_t h, int which, long *launches, double *total_ms)
 {
     if (!h || which < 0 || which >= GPCC_PROF_COUNT) return fail(h, GPCC_ERR_ARGUMENT, "bad argument");
+    h = primary(h);
     prof_collect(h);
     if (launches) *launches = h->prof_n[which];
     if (total_ms) *total_ms = h->prof_ms[which];
@@ -1005,8 +1294,8 @@ extern "C" int gpcc_profile_get(gpcc_handle_t h, int which, long *launches, doub
 // ------------------------------------------------------------------------------------------
 extern "C" int gpcc_selftest(int device_id, double *tflops)
 {
-    int rc = set_device(nullptr, device_id);
-    if (rc) return rc;
+    GPCC_ON_DEVICE(nullptr, device_id);
+    int rc = 0;
     double hA[64], hB[64], hD[256], ref[256];
     for (int i = 0; i < 16; ++i)
         for (int kk = 0; kk < 4; ++kk) hA[i * 4 + kk] = (double)(1 + i * 5 + kk * 3);  // asymmetric integers

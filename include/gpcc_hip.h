@@ -58,6 +58,26 @@ int gpcc_create(gpcc_handle_t *handle, int L, const int *Nl, const double *t, co
                 const double *sigma, int kernel_id, int marginalise_b, int precision, int device_id);
 int gpcc_destroy(gpcc_handle_t handle);
 
+/* The same for a list of devices of ONE process: the reference parallelises the delay-grid map
+ * with pmap workers (README.md:181-211, :258-287); here one handle owns a replica of the light curves on every listed
+ * device.  gpcc_loglik_batch and gpcc_grid_loglik then cut every batch into contiguous blocks, one host thread and
+ * one device per block, and collect [loglik | info] with ONE all-gather (RCCL over xGMI, ncclCommInitAll +
+ * ncclAllGather; no torch, no MPI), after which every device holds the whole vector (gpcc_multi_gathered).
+ * RCCL refuses a communicator with a repeated device: lists with duplicates (the one-GPU rehearsal {0, 0}) and
+ * single-entry lists gather through host memory instead; gpcc_get_option(h, "gather_mode") says which.
+ * A multi-device handle is accepted by every entry point that takes a handle, except gpcc_loglik_batch_device
+ * (device pointers belong to one device): the single-matrix utilities (gpcc_predict, gpcc_posterior_offsets,
+ * gpcc_model_matrix, gpcc_factor_dense, profiling) run on device_ids[0]; options apply to all devices. */
+enum { GPCC_GATHER_NONE = 0, GPCC_GATHER_RCCL = 1, GPCC_GATHER_HOST = 2 };
+int gpcc_create_multi(gpcc_handle_t *handle, int L, const int *Nl, const double *t, const double *y,
+                      const double *sigma, int kernel_id, int marginalise_b, int precision,
+                      const int *device_ids, int n_devices);
+
+/* The gathered vector of the last gpcc_loglik_batch as it sits on device `which` of a multi-device handle:
+ * n_devices blocks of [loglik(blk) | info-as-double(blk)], blk = ceil(M / n_devices) written to *blk_out
+ * (out == NULL only queries blk). */
+int gpcc_multi_gathered(gpcc_handle_t handle, int which, long *blk_out, double *out, long capacity);
+
 /* Tunables: "streams" (groups in flight on separate HIP streams, default 1), "slots_per_stream"
  * (evaluations resident per group, default 256 = one diagonal-block workgroup per CU, capped so
  * the workspace stays under 64 GiB), "right_looking_max" (groups of at most this many evaluations use
@@ -65,7 +85,8 @@ int gpcc_destroy(gpcc_handle_t handle);
  * batch whose evaluations all have the same band-1 amplitude, delay and rho -- a fixed-hyper-parameter delay
  * sweep, README.md:172-174 -- and then factorises the tile rows wholly inside band 1 once per group instead of
  * once per evaluation, results bitwise identical; 2 = the caller asserts that property, also for the _device
- * form).  gpcc_get_option also answers "N", "Np", "precision", "bytes_per_slot", "share_tiles". */
+ * form).  gpcc_get_option also answers "N", "Np", "precision", "bytes_per_slot", "share_tiles", "n_devices",
+ * "gather_mode". */
 int gpcc_set_option(gpcc_handle_t handle, const char *key, long value);
 long gpcc_get_option(gpcc_handle_t handle, const char *key);
 

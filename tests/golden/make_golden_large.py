@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/gpcc_golden_large.json: scalar log-likelihoods at the BASELINE.json sizes.
+
+Same independent numpy/scipy restatement as make_golden.py (broadcasting + LAPACK dpotrf/dtrtrs, no code
+shared with oracle/*.c or with the HIP path), applied to the workloads of BASELINE.json configs 2-5.  The
+light curves are NOT stored (up to 3 x 16384 doubles): they are regenerated from gpcc_amd.synthetic with the
+recorded seed, and a checksum of the regenerated data is stored so a test can tell "the generator drifted"
+from "the device result is wrong".  Stored per case: shape, seed, kernel, b-mode, delays, alpha, rho, loglik.
+
+  cfg2  2 x 1024  Matern-3/2            fp64   2 delays
+  cfg3  2 x 2048  OU/rbf/matern32/52    fp64   3 delays each (+ one fixed-b case)
+  cfg4  3 x 1365  Matern-3/2            fp64   2 delay pairs
+  cfg5  2 x 8192  Matern-5/2            (fp32 on the device; the golden value is fp64)   2 delays
+  plus ill-conditioned N = 2048 cases (sigma = 0.05, alpha up to 100) for the fp32 accuracy bar.
+
+PARITY UNPINNED against the real reference (no Julia in this image); see DESIGN.md "Oracle".
+Run from the repo root (minutes; the N = 16384 cases need ~10 GB):  python tests/golden/make_golden_large.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from make_golden import objective  # noqa: E402  (the scipy restatement)
+
+from gpcc_amd import synthetic  # noqa: E402  (numpy-only generator, no device code)
+
+
+def checksum(t, y, s):
+    return [float(np.sum(np.concatenate(t))), float(np.sum(np.concatenate(y))), float(np.sum(np.concatenate(s) ** 2))]
+
+
+def main():
+    cases = []
+
+    def add(tag, Nl, seed, kernel, mb, delay_rows, alpha=None, rho=None, sigma=0.75):
+        t, y, s, _ = synthetic.simulate_lightcurves(Nl, seed=seed, sigma=sigma)
+        a0, r0 = synthetic.default_hyperparameters(y)
+        a = np.asarray(a0 if alpha is None else alpha, dtype=float)
+        r = float(r0 if rho is None else rho)
+        for d in delay_rows:
+            ll, info = objective(kernel, t, y, s, np.asarray(d, dtype=float), a, r, mb)
+            assert info == 0
+            cases.append(dict(tag=tag, Nl=list(Nl), seed=seed, sigma=sigma, kernel=kernel, marginalise_b=mb,
+                              delays=list(map(float, d)), alpha=a.tolist(), rho=r, loglik=ll,
+                              data_checksum=checksum(t, y, s)))
+            print(tag, kernel, mb, d, ll, flush=True)
+
+    add("cfg2", [1024, 1024], 1, "matern32", True, [[0.0, 2.0], [0.0, 11.3]])
+    for k in ("OU", "rbf", "matern32", "matern52"):
+        add("cfg3", [2048, 2048], 1, k, True, [[0.0, 0.0], [0.0, 2.0], [0.0, 13.7]])
+    add("cfg3", [2048, 2048], 2, "matern32", False, [[0.0, 2.0]])
+    add("cfg4", [1365, 1365, 1365], 1, "matern32", True, [[0.0, 2.0, 4.0], [0.0, 0.5, 6.0]])
+    # ill-conditioned for fp32: small noise, large amplitudes (cond(K0) ~ alpha^2 N / sigma^2)
+    add("illcond", [1024, 1024], 3, "matern32", True, [[0.0, 2.0]], alpha=[5.0, 5.0], rho=3.5, sigma=0.05)
+    add("illcond", [1024, 1024], 3, "matern52", True, [[0.0, 2.0]], alpha=[100.0, 60.0], rho=8.0, sigma=0.75)
+    add("illcond", [1024, 1024], 3, "OU", False, [[0.0, 2.0]], alpha=[30.0, 100.0], rho=20.0, sigma=0.3)
+    add("illcond", [1024, 1024], 3, "rbf", True, [[0.0, 2.0]], alpha=[3.0, 2.0], rho=0.3, sigma=0.05)
+    add("cfg5", [8192, 8192], 1, "matern52", True, [[0.0, 2.0], [0.0, 13.7]])
+    out = dict(note="independent numpy/scipy (LAPACK) restatement at BASELINE sizes; light curves regenerated from "
+                    "gpcc_amd.synthetic seeds; reference not executable (no Julia); parity unpinned",
+               numpy=np.__version__, cases=cases)
+    with open(os.path.join(HERE, "gpcc_golden_large.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote %d cases" % len(cases))
+
+
+if __name__ == "__main__":
+    main()
