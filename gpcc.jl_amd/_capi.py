@@ -14,7 +14,7 @@ c_long_p = ctypes.POINTER(ctypes.c_long)
 
 KERNEL_IDS = {"OU": 0, "rbf": 1, "matern32": 2, "matern52": 3}
 PRECISION_IDS = {"fp64": 0, "fp32": 1}
-PROF_NAMES = ("assemble", "panel_update", "diag_factor", "panel_trsm")
+PROF_NAMES = ("assemble", "panel_update", "diag_factor", "panel_trsm", "refine")
 
 # every symbol include/gpcc_hip.h declares: name -> (restype, argtypes)
 BATCH_OBJECTIVE = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.POINTER(ctypes.c_long),
@@ -32,6 +32,7 @@ SIGNATURES = {
     "gpcc_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_long]),
     "gpcc_get_option": (ctypes.c_long, [ctypes.c_void_p, ctypes.c_char_p]),
     "gpcc_get_constants": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, c_double_p]),
+    "gpcc_get_conditioning": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p]),
     "gpcc_loglik_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p, c_double_p,
                                          c_double_p, c_int_p]),
     "gpcc_loglik_batch_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,

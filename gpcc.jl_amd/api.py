@@ -203,6 +203,12 @@ class Objective:
         self._chk(_capi.load().gpcc_get_constants(self._h, _dp(mu), _dp(sb), _dp(r)))
         return mu, sb, r
 
+    def conditioning(self, M):
+        """fp32 handles: (M, 2) array [sum_i K_ii/d_i, max_i K_ii/d_i] of the last batch (gpcc_get_conditioning)."""
+        out = np.empty((int(M), 2), dtype=np.float64)
+        self._chk(_capi.load().gpcc_get_conditioning(self._h, int(M), _dp(out)))
+        return out
+
     def gathered(self, which=0):
         """Multi-device handles: the all-gathered [loglik | info] blocks of the last loglik_batch as they sit on
         device `which` -> (loglik[n_devices, blk], info[n_devices, blk]) (padding: NaN / 0)."""

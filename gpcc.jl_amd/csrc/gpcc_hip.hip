@@ -45,15 +45,29 @@ struct gpcc_handle_s {
     double *d_tiles = nullptr, *d_linv = nullptr, *d_z = nullptr, *d_w = nullptr, *d_logdet = nullptr,
            *d_quad = nullptr;   // d_quad: Gram matrices (slots x MAXRHS^2)
     int *d_info = nullptr;
+    double *d_kdiag = nullptr, *d_cond = nullptr;   // fp32 mode: diag(K) as assembled, pivot-ratio sums (GpccCtx)
+    double *d_gpart = nullptr;                      // fp32 mode: per-tile partials of X' K0 X (refinement)
+    int fp32_refine = 1;                            // option "fp32_refine": 0 = no refinement of the quadratic forms
     long slot_stride = 0;
     hipStream_t str[GPCC_MAX_STREAMS] = {};
     hipEvent_t ev_done[GPCC_MAX_STREAMS] = {};
     hipEvent_t ev_start = nullptr;
     hipStream_t main_stream = nullptr;
     // staging for the host-pointer API
-    double *d_par = nullptr, *d_out = nullptr;
+    double *d_par = nullptr, *d_out = nullptr, *d_ocond = nullptr;
     int *d_oinfo = nullptr;
     long par_cap = 0;
+    // fp32 mode: a-posteriori accuracy guard.  Every evaluation reports the sum and the maximum of
+    // K_ii / d_i over its pivots; where the error model built on them exceeds the budget, the evaluation is repeated
+    // on an internal fp64 handle (`fb`, created on first use) and its result replaces the fp32 one.
+    int fp32_guard = 1;              // option "fp32_guard": 0 = raw fp32 results
+    long cond_cap = 0, fb_cap = 0;
+    int *d_fb_idx = nullptr, *d_fb_info = nullptr;
+    double *d_fb_par = nullptr, *d_fb_out = nullptr;
+    gpcc_handle_t fb = nullptr;
+    long fb_count = 0;               // evaluations repeated in fp64 so far ("fp32_guard_count")
+    std::vector<double> cond_host, ll_host, sigma_host;
+    std::vector<int> info_host, fb_idx_host;
     // profiling
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -182,7 +196,7 @@ extern "C" int gpcc_create(gpcc_handle_t *out, int L, const int *Nl, const doubl
     h->nrhs = h->woodbury ? L + 1 : 1;
     h->share_tiles = (L >= 2) ? Nl[0] / GPCC_TILE : 0;
     {   // default group size: 256 evaluations resident (one per CU in the diagonal step), capped at 64 GiB
-        const double per_slot = ((double)h->nt * (h->nt + 1) / 2 + 1) * GPCC_TILE_ELEMS * (precision ? 4.0 : 8.0) + 16.0 * h->Np * (L + 1);
+        const double per_slot = ((double)h->nt * (h->nt + 1) / 2 + (precision ? h->nt : 1)) * GPCC_TILE_ELEMS * (precision ? 4.0 : 8.0) + 16.0 * h->Np * (L + 1);
         long cap = (long)(64.0 * 1024 * 1024 * 1024 / per_slot);
         if (cap < 8) cap = 8;
         if (h->slots_per_stream > cap) h->slots_per_stream = (int)(cap / 8 * 8);
@@ -213,6 +227,7 @@ extern "C" int gpcc_create(gpcc_handle_t *out, int L, const int *Nl, const doubl
     h->t_host.assign(ht.begin(), ht.begin() + N);
     h->y_host.assign(hy.begin(), hy.begin() + N);
     h->sig2_host.assign(hs.begin(), hs.begin() + N);
+    h->sigma_host.assign(sigma, sigma + N);
     h->band_host.assign(hb.begin(), hb.begin() + N);
 #define CR(call)                                                                                             \
     do {                                                                                                     \
@@ -244,8 +259,8 @@ extern "C" int gpcc_create(gpcc_handle_t *out, int L, const int *Nl, const doubl
 static void free_workspace(gpcc_handle_t h)
 {
     hipFree(h->d_tiles); hipFree(h->d_linv); hipFree(h->d_z); hipFree(h->d_w);
-    hipFree(h->d_logdet); hipFree(h->d_quad); hipFree(h->d_info);
-    h->d_tiles = h->d_linv = h->d_z = h->d_w = h->d_logdet = h->d_quad = nullptr;
+    hipFree(h->d_logdet); hipFree(h->d_quad); hipFree(h->d_info); hipFree(h->d_kdiag); hipFree(h->d_cond); hipFree(h->d_gpart);
+    h->d_tiles = h->d_linv = h->d_z = h->d_w = h->d_logdet = h->d_quad = h->d_kdiag = h->d_cond = h->d_gpart = nullptr;
     h->d_info = nullptr;
     for (int s = 0; s < GPCC_MAX_STREAMS; ++s) {
         if (h->str[s]) { hipStreamDestroy(h->str[s]); h->str[s] = nullptr; }
@@ -264,6 +279,8 @@ extern "C" int gpcc_destroy(gpcc_handle_t h)
     free_workspace(h);
     hipFree(h->d_t); hipFree(h->d_sig2); hipFree(h->d_resid); hipFree(h->d_band); hipFree(h->d_yv);
     hipFree(h->d_par); hipFree(h->d_out); hipFree(h->d_oinfo);
+    hipFree(h->d_ocond); hipFree(h->d_fb_idx); hipFree(h->d_fb_par); hipFree(h->d_fb_out); hipFree(h->d_fb_info);
+    if (h->fb) gpcc_destroy(h->fb);
     if (h->main_stream) hipStreamDestroy(h->main_stream);
     if (h->ev_start) hipEventDestroy(h->ev_start);
     delete h;
@@ -288,6 +305,10 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->slots_per_stream = (int)v;
     } else if (!strcmp(key, "right_looking_max")) {
         h->right_looking_max = (int)v;
+    } else if (!strcmp(key, "fp32_guard")) {
+        h->fp32_guard = v != 0;
+    } else if (!strcmp(key, "fp32_refine")) {
+        h->fp32_refine = v != 0;
     } else if (!strcmp(key, "shared_prefix")) {
         if (v < 0 || v > 2) return fail(h, GPCC_ERR_ARGUMENT, "shared_prefix must be 0, 1 or 2");
         h->shared_prefix = (int)v;
@@ -310,8 +331,11 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "share_tiles")) return h->share_tiles;
     if (!strcmp(key, "N")) return h->N;
     if (!strcmp(key, "Np")) return h->Np;
-    if (!strcmp(key, "bytes_per_slot")) return (long)(((long)h->nt * (h->nt + 1) / 2 + 1) * GPCC_TILE_ELEMS) * (h->precision ? 4 : 8) + 16L * h->Np * h->nrhs;
+    if (!strcmp(key, "bytes_per_slot")) return (long)(((long)h->nt * (h->nt + 1) / 2 + (h->precision ? h->nt : 1)) * GPCC_TILE_ELEMS) * (h->precision ? 4 : 8) + 16L * h->Np * h->nrhs;
     if (!strcmp(key, "precision")) return h->precision;
+    if (!strcmp(key, "fp32_guard")) return h->fp32_guard;
+    if (!strcmp(key, "fp32_refine")) return h->fp32_refine;
+    if (!strcmp(key, "fp32_guard_count")) return h->fb_count;
     return -1;
 }
 
@@ -322,6 +346,16 @@ extern "C" int gpcc_get_constants(gpcc_handle_t h, double *mean_b, double *Sigma
     if (mean_b) memcpy(mean_b, h->mean_b, sizeof(double) * h->L);
     if (Sigma_b) memcpy(Sigma_b, h->sigma_b, sizeof(double) * h->L);
     if (resid) memcpy(resid, h->resid_host.data(), sizeof(double) * h->N);
+    return 0;
+}
+
+extern "C" int gpcc_get_conditioning(gpcc_handle_t h, int M, double *out)
+{
+    if (!h || !out || M < 0) return fail(h, GPCC_ERR_ARGUMENT, "bad argument");
+    h = primary(h);
+    if (h->precision != GPCC_PRECISION_FP32) return fail(h, GPCC_ERR_ARGUMENT, "pivot ratios are tracked by fp32 handles only");
+    if ((size_t)2 * M > h->cond_host.size()) return fail(h, GPCC_ERR_ARGUMENT, "the last batch had %ld evaluations", (long)(h->cond_host.size() / 2));
+    memcpy(out, h->cond_host.data(), sizeof(double) * 2 * M);
     return 0;
 }
 
@@ -349,12 +383,17 @@ static int ensure_workspace(gpcc_handle_t h)
     h->slot_stride = ((long)h->nt * (h->nt + 1) / 2) * GPCC_TILE_ELEMS;
     const size_t esz = h->precision ? sizeof(float) : sizeof(double);
     HIPCHK(h, hipMalloc(&h->d_tiles, esz * h->slot_stride * slots));
-    HIPCHK(h, hipMalloc(&h->d_linv, esz * GPCC_TILE_ELEMS * slots));
+    HIPCHK(h, hipMalloc(&h->d_linv, esz * GPCC_TILE_ELEMS * slots * (h->precision == GPCC_PRECISION_FP32 ? h->nt : 1)));
     HIPCHK(h, hipMalloc(&h->d_z, sizeof(double) * h->Np * h->nrhs * slots));
     HIPCHK(h, hipMalloc(&h->d_w, sizeof(double) * h->Np * h->nrhs * slots));
     HIPCHK(h, hipMalloc(&h->d_logdet, sizeof(double) * slots));
     HIPCHK(h, hipMalloc(&h->d_quad, sizeof(double) * GPCC_MAXRHS * GPCC_MAXRHS * slots));
     HIPCHK(h, hipMalloc(&h->d_info, sizeof(int) * slots));
+    if (h->precision == GPCC_PRECISION_FP32) {
+        HIPCHK(h, hipMalloc(&h->d_kdiag, sizeof(double) * h->Np * slots));
+        HIPCHK(h, hipMalloc(&h->d_cond, sizeof(double) * 2 * slots));
+        HIPCHK(h, hipMalloc(&h->d_gpart, sizeof(double) * GPCC_MAXRHS * GPCC_MAXRHS * ((long)h->nt * (h->nt + 1) / 2) * slots));
+    }
     for (int s = 0; s < h->streams; ++s) {
         HIPCHK(h, hipStreamCreateWithFlags(&h->str[s], hipStreamNonBlocking));
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_done[s], hipEventDisableTiming));
@@ -371,6 +410,8 @@ static GpccCtx make_ctx(gpcc_handle_t h)
     GpccCtx c;
     c.tiles = h->d_tiles; c.linv = h->d_linv; c.z = h->d_z; c.w = h->d_w;
     c.logdet = h->d_logdet; c.gram = h->d_quad; c.info = h->d_info;
+    c.kdiag = h->d_kdiag; c.cond = h->d_cond; c.gpart = h->d_gpart;
+    c.linv_keep = (h->precision == GPCC_PRECISION_FP32) ? 1 : 0;
     c.t = h->d_t; c.sig2 = h->d_sig2; c.resid = h->d_resid; c.band = h->d_band; c.yv = h->d_yv;
     for (int l = 0; l < GPCC_MAXL; ++l) c.sigma_b[l] = (l < h->L) ? h->sigma_b[l] : 0.0;
     c.slot_stride = h->slot_stride;
@@ -419,7 +460,23 @@ static int enqueue_group(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, 
     const bool single = (f32 < 0) ? (h->precision == GPCC_PRECISION_FP32) : (f32 != 0);
     launch_assemble(h, c, g, s, ext, single);
     if (!factor) return 0;
-    return enqueue_factor(h, c, g, s, single);
+    int rc = enqueue_factor(h, c, g, s, single);
+    if (rc || !single || !h->fp32_refine || !c.gpart || !c.linv_keep) return rc;
+    {   // fp32: refine the quadratic forms in fp64 -- backward solve, X' K0 X on the fly, final arithmetic
+        ProfScope pr(h, GPCC_PROF_REFINE, s);
+        gpcc_back_solve<float><<<g.cnt, 512, 0, s>>>(c, g);
+        dim3 grid(c.nt * c.nt, g.cnt);
+        switch (c.kernel_id) {
+        case 0: gpcc_refine_partials<0><<<grid, 256, 0, s>>>(c, g); break;
+        case 1: gpcc_refine_partials<1><<<grid, 256, 0, s>>>(c, g); break;
+        case 2: gpcc_refine_partials<2><<<grid, 256, 0, s>>>(c, g); break;
+        default: gpcc_refine_partials<3><<<grid, 256, 0, s>>>(c, g); break;
+        }
+        gpcc_refine_finish<<<g.cnt, 256, 0, s>>>(c, g);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, GPCC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return 0;
 }
 
 template <typename T>
@@ -470,20 +527,13 @@ static int enqueue_factor(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g,
     return 0;
 }
 
-extern "C" int gpcc_loglik_batch_device(gpcc_handle_t h, int M, const double *d_delays, const double *d_alpha,
-                                        const double *d_rho, double *d_loglik, int *d_info, void *stream)
+// M evaluations, device pointers, enqueued behind `caller` and joined back into it; d_cond (2 per evaluation, fp32
+// handles) may be NULL.  The calling thread holds the device.
+static int enqueue_batch(gpcc_handle_t h, int M, const double *d_delays, const double *d_alpha, const double *d_rho,
+                         double *d_loglik, int *d_info, double *d_cond, hipStream_t caller)
 {
-    if (!h) return fail(h, GPCC_ERR_ARGUMENT, "NULL handle");
-    if (M < 0) return fail(h, GPCC_ERR_ARGUMENT, "M=%d < 0", M);
-    if (M == 0) return 0;
-    if (!d_delays || !d_alpha || !d_rho || !d_loglik || !d_info) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
-    if (h->is_multi()) return fail(h, GPCC_ERR_UNSUPPORTED, "a multi-device handle takes host pointers (gpcc_loglik_batch): device pointers belong to one device");
-    GPCC_ON_DEVICE(h, h->device);
-    int rc = stream_on_device(h, stream, h->device);
+    int rc = ensure_workspace(h);
     if (rc) return rc;
-    rc = ensure_workspace(h);
-    if (rc) return rc;
-    hipStream_t caller = (hipStream_t)stream;
     if (!h->share_now) h->share_now = (h->shared_prefix == 2);   // device pointers cannot be inspected: only on assertion
     const GpccCtx c = make_ctx(h);
     const int S = h->prof ? 1 : h->streams;  // profiling serialises groups onto one stream
@@ -496,7 +546,7 @@ extern "C" int gpcc_loglik_batch_device(gpcc_handle_t h, int M, const double *d_
         const int s = gi % S;
         GpccGroup g;
         g.delays = d_delays; g.alpha = d_alpha; g.rho = d_rho;
-        g.out_loglik = d_loglik; g.out_info = d_info;
+        g.out_loglik = d_loglik; g.out_info = d_info; g.out_cond = d_cond;
         g.first = gi * cs;
         g.slot0 = s * cs;
         g.cnt = (M - g.first < cs) ? (M - g.first) : cs;
@@ -512,6 +562,128 @@ extern "C" int gpcc_loglik_batch_device(gpcc_handle_t h, int M, const double *d_
         HIPCHK(h, hipStreamWaitEvent(caller, h->ev_done[s], 0));
     }
     h->share_now = false;
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// fp32 accuracy guard.  An fp32 blocked Cholesky (fp64 diagonal blocks, fp64 right-hand sides) computes
+// L~ L~' = K0 + E with |E_ij| <= gamma sqrt(K_ii K_jj), gamma between u32 and N u32; to first order the log-likelihood
+// moves by -(tr(K0^-1 E) - w' E w) / 2 (w = K0^-1 r).  The w' E w part (10-100x the other) is removed by the fp64
+// refinement of the quadratic forms (gpcc_back_solve / gpcc_refine_partials / gpcc_refine_finish); what is left grows
+// with the pivot ratios K_ii / d_i >= 1 (d_i = L_ii^2, the Schur complement a pivot sees; (K0^-1)_ii >= 1 / d_i), and
+// once u32 times the condition number approaches 1 the factor is useless and the refinement with it.
+// gpcc_diag_factor therefore accumulates S = sum_i K_ii / d_i per evaluation, and an evaluation whose MEAN PIVOT RATIO
+// S / N exceeds a limit is repeated in fp64.  Calibration (tools/calibrate_fp32.py against the fp64 path, N 1..4096,
+// 1-6 bands, all kernels, both b-modes, sigma 0.05..1, alpha 1e-2..1e2, rho 0.1..300; raw fp32 errors in that set reach
+// 0.37, refined ones 23 where the factor is garbage):
+//   refined   (profiles/r02/fp32_refined_calibration.log.gz, 43 484 evaluations): worst error among S/N <= 300 is
+//             2.1e-5, among S/N <= 1000 1.3e-4, among S/N <= 2000 2.6e-3               -> limit 300 (50x below the bar)
+//   unrefined (profiles/r02/fp32_guard_calibration.log.gz, 45 214 evaluations): worst error among S/N <= 50 is 3.6e-4,
+//             among S/N <= 100 6.5e-4 (and a soak case at 1.06e-3 below 74)             -> limit 30
+// The benchmark's own regime (sigma = 0.75, alpha = var(y)) has S/N ~ 15-45, up to ~150 with alpha scaled by 2.
+// A measure fitted to a random sample, not a proof; "fp32_guard" = 0 switches it off.
+// ------------------------------------------------------------------------------------------
+#define GPCC_FP32_LIMIT_REFINED 300.0
+#define GPCC_FP32_LIMIT_RAW 30.0
+static inline bool fp32_needs_fp64(double S, int N, bool refined)
+{
+    return !(S <= (refined ? GPCC_FP32_LIMIT_REFINED : GPCC_FP32_LIMIT_RAW) * (double)(N > 0 ? N : 1));   // NaN -> true
+}
+
+__global__ void gpcc_gather_params(int nf, int L, const int *idx, const double *delays, const double *alpha, const double *rho,
+                                   double *out /* nf x L | nf x L | nf */)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nf) return;
+    const long src = idx[i];
+    for (int l = 0; l < L; ++l) {
+        out[(long)i * L + l] = delays[src * L + l];
+        out[(long)nf * L + (long)i * L + l] = alpha[src * L + l];
+    }
+    out[2L * nf * L + i] = rho[src];
+}
+
+__global__ void gpcc_scatter_results(int nf, const int *idx, const double *ll, const int *info, double *out_ll, int *out_info)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nf) return;
+    out_ll[idx[i]] = ll[i];
+    out_info[idx[i]] = info[i];
+}
+
+static int fp32_guard_pass(gpcc_handle_t h, int M, const double *d_delays, const double *d_alpha, const double *d_rho,
+                           double *d_loglik, int *d_info, hipStream_t caller)
+{
+    // read the fp32 results and their conditioning back (the one synchronisation an fp32 handle adds per call)
+    h->cond_host.resize(2 * (size_t)M);
+    h->ll_host.resize(M);
+    h->info_host.resize(M);
+    HIPCHK(h, hipMemcpyAsync(h->cond_host.data(), h->d_ocond, sizeof(double) * 2 * M, hipMemcpyDeviceToHost, caller));
+    HIPCHK(h, hipMemcpyAsync(h->ll_host.data(), d_loglik, sizeof(double) * M, hipMemcpyDeviceToHost, caller));
+    HIPCHK(h, hipMemcpyAsync(h->info_host.data(), d_info, sizeof(int) * M, hipMemcpyDeviceToHost, caller));
+    HIPCHK(h, hipStreamSynchronize(caller));
+    if (!h->fp32_guard) return 0;
+    h->fb_idx_host.clear();
+    for (int i = 0; i < M; ++i)
+        // a pivot that is non-positive in fp32 may only be lost to rounding: fp64 decides (argument errors < 0 stay)
+        if (h->info_host[i] > 0 || (h->info_host[i] == 0 && fp32_needs_fp64(h->cond_host[2 * i], h->N, h->fp32_refine != 0)))
+            h->fb_idx_host.push_back(i);
+    const int nf = (int)h->fb_idx_host.size();
+    if (nf == 0) return 0;
+    if (!h->fb) {   // the literal fp64 model on the same light curves, a small workspace of its own
+        int rc = gpcc_create(&h->fb, h->L, h->Nl, h->t_host.data(), h->y_host.data(), h->sigma_host.data(), h->kernel_id, h->mb,
+                             GPCC_PRECISION_FP64, h->device);
+        if (rc) return fail(h, rc, "fp32 guard: creating the fp64 handle failed: %s", g_err.c_str());
+        const long per = gpcc_get_option(h->fb, "slots_per_stream");
+        gpcc_set_option(h->fb, "slots_per_stream", per < 16 ? per : 16);
+        gpcc_set_option(h->fb, "shared_prefix", 0);
+    }
+    if (nf > h->fb_cap) {
+        hipFree(h->d_fb_idx); hipFree(h->d_fb_par); hipFree(h->d_fb_out); hipFree(h->d_fb_info);
+        h->d_fb_idx = h->d_fb_info = nullptr; h->d_fb_par = h->d_fb_out = nullptr; h->fb_cap = 0;
+        const long cap = nf > 64 ? nf : 64;
+        HIPCHK(h, hipMalloc(&h->d_fb_idx, sizeof(int) * cap));
+        HIPCHK(h, hipMalloc(&h->d_fb_info, sizeof(int) * cap));
+        HIPCHK(h, hipMalloc(&h->d_fb_par, sizeof(double) * cap * (2 * h->L + 1)));
+        HIPCHK(h, hipMalloc(&h->d_fb_out, sizeof(double) * cap));
+        h->fb_cap = cap;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_fb_idx, h->fb_idx_host.data(), sizeof(int) * nf, hipMemcpyHostToDevice, caller));
+    gpcc_gather_params<<<(nf + 127) / 128, 128, 0, caller>>>(nf, h->L, h->d_fb_idx, d_delays, d_alpha, d_rho, h->d_fb_par);
+    int rc = gpcc_loglik_batch_device(h->fb, nf, h->d_fb_par, h->d_fb_par + (long)nf * h->L, h->d_fb_par + 2L * nf * h->L,
+                                      h->d_fb_out, h->d_fb_info, caller);
+    if (rc) return fail(h, rc, "fp32 guard: fp64 re-evaluation failed: %s", h->fb->err.c_str());
+    gpcc_scatter_results<<<(nf + 127) / 128, 128, 0, caller>>>(nf, h->d_fb_idx, h->d_fb_out, h->d_fb_info, d_loglik, d_info);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, GPCC_ERR_HIP, "fp32 guard: %s", hipGetErrorString(e));
+    HIPCHK(h, hipStreamSynchronize(caller));   // fb_idx_host / staging may be reused by the next call
+    h->fb_count += nf;
+    return 0;
+}
+
+extern "C" int gpcc_loglik_batch_device(gpcc_handle_t h, int M, const double *d_delays, const double *d_alpha,
+                                        const double *d_rho, double *d_loglik, int *d_info, void *stream)
+{
+    if (!h) return fail(h, GPCC_ERR_ARGUMENT, "NULL handle");
+    if (M < 0) return fail(h, GPCC_ERR_ARGUMENT, "M=%d < 0", M);
+    if (M == 0) return 0;
+    if (!d_delays || !d_alpha || !d_rho || !d_loglik || !d_info) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
+    if (h->is_multi()) return fail(h, GPCC_ERR_UNSUPPORTED, "a multi-device handle takes host pointers (gpcc_loglik_batch): device pointers belong to one device");
+    GPCC_ON_DEVICE(h, h->device);
+    int rc = stream_on_device(h, stream, h->device);
+    if (rc) return rc;
+    hipStream_t caller = (hipStream_t)stream;
+    const bool f32 = h->precision == GPCC_PRECISION_FP32;
+    if (f32 && M > h->cond_cap) {
+        hipFree(h->d_ocond);
+        h->d_ocond = nullptr; h->cond_cap = 0;
+        HIPCHK(h, hipMalloc(&h->d_ocond, sizeof(double) * 2 * M));
+        h->cond_cap = M;
+    }
+    rc = enqueue_batch(h, M, d_delays, d_alpha, d_rho, d_loglik, d_info, f32 ? h->d_ocond : nullptr, caller);
+    if (rc) return rc;
+    if (f32) return fp32_guard_pass(h, M, d_delays, d_alpha, d_rho, d_loglik, d_info, caller);
     return 0;
 }
 
@@ -632,6 +804,7 @@ static int run_augmented(gpcc_handle_t h, const double *delays, const double *al
     c.band = a.d_band;
     c.tiles = a.d_ws; c.linv = a.d_ws + stride; c.z = a.d_ws + stride + GPCC_TILE_ELEMS; c.w = c.z + Npa;
     c.logdet = c.w + Npa; c.gram = c.logdet + 1; c.info = a.d_info;
+    c.kdiag = nullptr; c.cond = nullptr; c.gpart = nullptr; c.linv_keep = 0;
     c.slot_stride = stride; c.Np = Npa; c.nt = nta; c.nt_fact = h->nt; c.marginalise_b = marginalise_b;
     c.nrhs = 1; c.woodbury = 0;   // the dense utilities always run the literal fp64 model
     c.store_l = 1;
@@ -643,7 +816,7 @@ static int run_augmented(gpcc_handle_t h, const double *delays, const double *al
     if (e == hipSuccess) e = hipMemcpyAsync(dr, &rho, sizeof(double), hipMemcpyHostToDevice, s);
     if (e != hipSuccess) { a.release(); return fail(h, GPCC_ERR_HIP, "augmented run: %s", hipGetErrorString(e)); }
     GpccGroup g;
-    g.delays = dd; g.alpha = da; g.rho = dr; g.out_loglik = h->d_out; g.out_info = h->d_oinfo;
+    g.delays = dd; g.alpha = da; g.rho = dr; g.out_loglik = h->d_out; g.out_info = h->d_oinfo; g.out_cond = nullptr;
     g.first = 0; g.slot0 = 0; g.cnt = 1; g.spread = 0;
     const bool was_prof = h->prof;
     h->prof = false;
@@ -732,6 +905,8 @@ extern "C" int gpcc_posterior_offsets(gpcc_handle_t h, const double *delays, con
     if (!h || !delays || !alpha || !mu_postb || !Sigma_postb) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
     h = primary(h);
     if (!h->mb) return fail(h, GPCC_ERR_ARGUMENT, "the fixed-b variant (gpccfixdelay.jl) has no posterior over offsets");
+    for (int l = 0; l < h->L; ++l)   // Sigma_b[l] = 100 var(y_l) = 0: inv(Sigma_b) of marginaliseb.jl:248 does not exist
+        if (!(h->sigma_b[l] > 0.0)) return fail(h, GPCC_ERR_ARGUMENT, "band %d has zero flux variance: the prior of its offset is degenerate (Sigma_b singular)", l + 1);
     const int L = h->L, ne = L + 1;
     std::vector<int> eb(ne);
     for (int e = 0; e < ne; ++e) eb[e] = -2 - e;          // rows Q[:,0..L-1] and Y against (Sobs + K), no B term

@@ -22,7 +22,8 @@
 #define GPCC_DIAG_LD 130
 #define GPCC_DINV_LD 17
 #define GPCC_DIAG_LDS_BYTES \
-    ((GPCC_TILE * GPCC_DIAG_LD + 8 * 16 * GPCC_DINV_LD + GPCC_MAXRHS * GPCC_TILE + GPCC_TILE + GPCC_MAXRHS * GPCC_MAXRHS + 3) * 8 + 16)
+    ((GPCC_TILE * GPCC_DIAG_LD + 8 * 16 * GPCC_DINV_LD + GPCC_MAXRHS * GPCC_TILE + 2 * GPCC_TILE + GPCC_MAXRHS * GPCC_MAXRHS + 3) * 8 + 16)
+static_assert(GPCC_DIAG_LDS_BYTES <= 160 * 1024, "gpcc_diag_factor's LDS image must fit the 160 KiB of a gfx950 CU");
 #define GPCC_GEMM_LDS_BYTES (2 * 2 * GPCC_CHUNK_BYTES)
 #define GPCC_GEMM_THREADS 512
 #define GPCC_RIGHT_LOOKING_MAX 24
@@ -65,6 +66,12 @@ struct GpccCtx {
     double *logdet;  // slots             : sum_i log L_ii
     double *gram;    // slots x nrhs^2    : W^T W  (nrhs = 1: |w|^2 = sqmahal)
     int *info;       // slots
+    double *gpart;   // slots x nt(nt+1)/2 x nrhs^2 : per-tile partial sums of X' K0 X (fp32 refinement, gpcc_refine_partials)
+    int linv_keep;   // 1: linv holds ALL nt inverses of a slot (slot*nt + k), kept for the backward solve of the fp32
+                     //    refinement; 0: one tile per slot, overwritten every step
+    double *kdiag;   // slots x Np : diag(K) as assembled, fp64 (fp32 mode only: numerator of the pivot ratios below)
+    double *cond;    // slots x 2  : sum_i K_ii / d_i and max_i K_ii / d_i over the pivots d_i (fp32 mode only) -- the
+                     //              a-posteriori conditioning measure behind the fp64 re-evaluation, DESIGN.md 4.7
     const double *t, *sig2, *resid;  // Np (padding: 0)
     const double *yv;                // Np: raw fluxes (only read by explicit 'Y' rows, see band codes)
     const int *band;                 // Np: >= 0 band of a real point; -1 identity padding;
@@ -87,6 +94,7 @@ struct GpccGroup {
     const double *delays, *alpha, *rho;  // whole-batch arrays (M x L, M x L, M)
     double *out_loglik;                  // whole-batch outputs
     int *out_info;
+    double *out_cond;                    // 2 per evaluation (see GpccCtx::cond) or NULL
     int first;  // index of this group's first evaluation in the batch arrays
     int slot0;  // first slot of the stream that runs this group
     int cnt;    // evaluations in this group
@@ -97,6 +105,10 @@ struct GpccGroup {
 __device__ __forceinline__ long gpcc_tile_off(int I, int J)
 {
     return ((long)I * (I + 1) / 2 + J) * GPCC_TILE_ELEMS;
+}
+__device__ __forceinline__ long gpcc_linv_off(const GpccCtx &c, int slot, int k)
+{
+    return (c.linv_keep ? ((long)slot * c.nt + k) : (long)slot) * GPCC_TILE_ELEMS;
 }
 // Slot swizzle of row r (depends on row bits 1..3).  ds_read_b128 is served in 16-lane groups
 // {q even, rows 0-3,12-15 | q odd, rows 4-11} (and the mirrored one); g maps the row pairs
@@ -218,6 +230,7 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
         c.info[slot] = bad;
         c.logdet[slot] = 0.0;
         for (int i = 0; i < c.nrhs * c.nrhs; ++i) c.gram[(long)slot * GPCC_MAXRHS * GPCC_MAXRHS + i] = 0.0;
+        if (sizeof(T) == 4 && c.cond) c.cond[2 * (long)slot] = c.cond[2 * (long)slot + 1] = 0.0;
     }
     {
         const int side = tid >> 7, r = tid & 127;
@@ -296,6 +309,8 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
                         val = 0.0;  // never read: explicit points come last, so they are rows of the lower triangle
                     }
                 }
+                if (sizeof(T) == 4 && diag && r == cc && c.kdiag)   // unrounded diagonal of a real point (0: padding)
+                    c.kdiag[(long)slot * c.Np + I * GPCC_TILE + r] = (br >= 0) ? val : 0.0;
                 v[h] = (T)val;
             }
             *(typename P::v16 *)(Tt + ch * (GPCC_TILE * P::KC) + r * P::KC + sp * P::EP) = v;
@@ -503,7 +518,7 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_trsm(GpccCtx c, GpccGroup g
     T *tiles = (T *)c.tiles + (long)slot * c.slot_stride;
     T *Tt = tiles + gpcc_tile_off(I, k);
     const T *gA = Tt;                                                // the chunks of T(I,k), overwritten at the end
-    const T *gB = (const T *)c.linv + (long)lslot * GPCC_TILE_ELEMS;  // inv(L_kk): rows = output column, k = j
+    const T *gB = (const T *)c.linv + gpcc_linv_off(c, lslot, k);  // inv(L_kk): rows = output column, k = j
 
     gpcc_dma_chunk<T>(gA, gB, smem, wave, lane);
     typename P::acc_t acc[8];
@@ -608,6 +623,55 @@ __device__ __forceinline__ double gpcc_rsqrt(double d)
     return __builtin_fma(y, r, y);
 }
 
+// loglik = -(N log 2pi + logdet K)/2 - (Y-bbar)' K^-1 (Y-bbar)/2  (Distributions.logpdf, marginaliseb.jl:139) from
+// ld = sum_i log L_ii and the Gram matrix G = W'W of the whitened right-hand sides (nrhs x nrhs, modified in place).
+// woodbury: the matrix that was factorised is K0 and R = [Q | r]:
+//   K = K0 + Q Sigma_b Q':  logdet K = logdet K0 + sum log Sigma_b + logdet M,
+//   r'K^-1 r = r'K0^-1 r - v' M^-1 v,  M = Sigma_b^-1 + Q'K0^-1 Q, v = Q'K0^-1 r   (all entries of G);
+// a non-positive pivot of M sets bad = N + 1 + j.
+__device__ __forceinline__ double gpcc_loglik_from_gram(const GpccCtx &c, double *sG, int nrhs, double ld, int &bad)
+{
+            const double log2pi = 1.8378770664093454835606594728112;
+            double logdetK = 2.0 * ld, quad = sG[nrhs * nrhs - 1];
+            if (c.woodbury && !bad) {
+                // K = K0 + Q Sigma_b Q':  logdet K = logdet K0 + sum log Sigma_b + logdet M,
+                // r'K^-1 r = r'K0^-1 r - v' M^-1 v,  M = Sigma_b^-1 + Q'K0^-1 Q, v = Q'K0^-1 r   (all from W'W)
+                // (in place in the LDS copy of the Gram matrix: M(a,b) = sG[a*nrhs+b], v(a) = sG[a*nrhs+L])
+                const int Lb = c.L;
+                for (int a = 0; a < Lb; ++a) {
+                    if (c.sigma_b[a] > 0.0) {
+                        sG[a * nrhs + a] += 1.0 / c.sigma_b[a];
+                        logdetK += log(c.sigma_b[a]);
+                    } else {
+                        // Sigma_b[a] = 0 (a band of constant fluxes): column a of Q contributes nothing to K; drop it
+                        // from the capacitance system (unit pivot, zero couplings) -- K = K0 + Sobs is still PD
+                        for (int p2 = 0; p2 <= Lb; ++p2) sG[a * nrhs + p2] = 0.0;
+                        for (int i = 0; i < Lb; ++i) sG[i * nrhs + a] = 0.0;
+                        sG[a * nrhs + a] = 1.0;
+                    }
+                }
+                for (int j = 0; j < Lb; ++j) {  // Cholesky of M + forward solve
+                    double d = sG[j * nrhs + j];
+                    for (int p2 = 0; p2 < j; ++p2) d -= sG[j * nrhs + p2] * sG[j * nrhs + p2];
+                    if (!(d > 0.0)) { bad = c.N + 1 + j; break; }
+                    d = sqrt(d);
+                    sG[j * nrhs + j] = d;
+                    for (int i = j + 1; i < Lb; ++i) {
+                        double s = sG[i * nrhs + j];
+                        for (int p2 = 0; p2 < j; ++p2) s -= sG[i * nrhs + p2] * sG[j * nrhs + p2];
+                        sG[i * nrhs + j] = s / d;
+                    }
+                    double s = sG[j * nrhs + Lb];
+                    for (int p2 = 0; p2 < j; ++p2) s -= sG[j * nrhs + p2] * sG[p2 * nrhs + Lb];
+                    s /= d;
+                    sG[j * nrhs + Lb] = s;
+                    logdetK += 2.0 * log(d);
+                    quad -= s * s;
+                }
+            }
+            return -((double)c.N * log2pi + logdetK) / 2.0 - quad / 2.0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c, GpccGroup g, int k)
 {
@@ -620,7 +684,8 @@ __global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c,
                                                 // X_b[r][c] at sDinv[(16 b + c) DLD + r] (a column of X_b is contiguous)
     double *sz = sDinv + 8 * 16 * DLD;          // nrhs x 128: Z_k, later W_k
     double *sr = sz + GPCC_MAXRHS * GPCC_TILE;  // [0, 80): wave 0's column scratch in (A); [96, 112): prod 1/L_jj per 16-block (mantissa, exponent)
-    double *sG = sr + GPCC_TILE;                // nrhs x nrhs Gram matrix
+    double *skd = sr + GPCC_TILE;               // diag(K) of this block's rows as assembled (fp32 mode)
+    double *sG = skd + GPCC_TILE;               // nrhs x nrhs Gram matrix
     double *sld = sG + GPCC_MAXRHS * GPCC_MAXRHS;   // sum log L_ii of this block
     int *sbad = (int *)(sG + GPCC_MAXRHS * GPCC_MAXRHS + 1);
 
@@ -665,6 +730,8 @@ __global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c,
     for (int e = tid; e < nrhs * GPCC_TILE; e += NT)
         sz[e] = c.z[((long)slot * nrhs + e / GPCC_TILE) * c.Np + k * GPCC_TILE + (e % GPCC_TILE)];
     if (tid == 0) *sbad = 0;
+    const bool track = sizeof(T) == 4 && c.kdiag != nullptr;   // fp32 mode: pivot ratios K_ii / d_i
+    if (track && tid < GPCC_TILE) skd[tid] = c.kdiag[(long)slot * c.Np + k * GPCC_TILE + tid];
 
     __syncthreads();   // tile and right-hand sides are in LDS
     // Software pipeline over the eight 16-column blocks.  Step jb: wave 0 folds column block jb-1 into the next
@@ -703,6 +770,7 @@ __global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c,
                 int bad = 0;
                 double py = 1.0;   // prod of the mantissas of 1/sqrt(d_j) (>= 2^-16) ...
                 int pe = 0;        // ... and the sum of their exponents: no overflow whatever the scale of K
+                double rs = 0.0, rm = 0.0;   // sum and max of K_ii / d_i over this block's pivots (fp32 mode only)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const double d = gpcc_bcast(v[j], j);
@@ -710,6 +778,11 @@ __global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c,
                     const double y = gpcc_rsqrt(d);
                     py *= __builtin_amdgcn_frexp_mant(y);   // off the chain: sum log L_jj of the block = -log prod 1/sqrt(d_j)
                     pe += __builtin_amdgcn_frexp_exp(y);
+                    if (sizeof(T) == 4 && track) {   // off the chain too
+                        const double ratio = skd[r0 + j] * (y * y);
+                        rs += ratio;
+                        rm = fmax(rm, ratio);
+                    }
                     v[j] *= y;               // lane j: L[j][j] = d / sqrt(d)
                     if (j < 15) {
                         // L[j+1][j] feeds the next pivot: v_readlane (short latency).  The other entries of the column go
@@ -732,6 +805,8 @@ __global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c,
                     if (lane == 0) {
                         sr[96 + jb] = py;
                         sr[104 + jb] = (double)pe;
+                        sr[112 + jb] = rs;
+                        sr[120 + jb] = rm;
                     }
                 }
             }
@@ -902,8 +977,21 @@ __global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c,
     if (c.share_p && k == c.share_p - 1) {
         // last step of the shared prefix (only the leader runs it): hand sum log L_ii and W'W over to the followers
         const double ldp = *sld + c.logdet[slot];   // same expression as the per-evaluation path below (bitwise identical results)
+        double cs = 0.0, cm = 0.0;
+        if (track) {
+            cs = c.cond[2 * (long)slot];
+            cm = c.cond[2 * (long)slot + 1];
+            for (int b = 0; b < 8; ++b) {
+                cs += sr[112 + b];
+                cm = fmax(cm, sr[120 + b]);
+            }
+        }
         for (int f = 1 + tid; f < g.cnt; f += NT) {
             c.logdet[g.slot0 + f] = ldp;
+            if (track) {
+                c.cond[2 * (long)(g.slot0 + f)] = cs;
+                c.cond[2 * (long)(g.slot0 + f) + 1] = cm;
+            }
             for (int i = 0; i < nrhs * nrhs; ++i) c.gram[(long)(g.slot0 + f) * GPCC_MAXRHS * GPCC_MAXRHS + i] = sG[i];
         }
         __syncthreads();   // everybody has read the leader's running sum before thread 0 updates it below
@@ -911,45 +999,29 @@ __global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c,
     if (tid == 0) {
         const double ld = *sld + c.logdet[slot];
         c.logdet[slot] = ld;
+        if (track) {
+            double cs = c.cond[2 * (long)slot], cm = c.cond[2 * (long)slot + 1];
+            for (int b = 0; b < 8; ++b) {
+                cs += sr[112 + b];
+                cm = fmax(cm, sr[120 + b]);
+            }
+            c.cond[2 * (long)slot] = cs;
+            c.cond[2 * (long)slot + 1] = cm;
+            if (last && g.out_cond) {
+                g.out_cond[2 * (long)(g.first + m)] = cs;
+                g.out_cond[2 * (long)(g.first + m) + 1] = cm;
+            }
+        }
         int bad = *sbad;
         if (bad) c.info[slot] = k * GPCC_TILE + bad;
         if (last) {
-            const double log2pi = 1.8378770664093454835606594728112;
-            double logdetK = 2.0 * ld, quad = sG[nrhs * nrhs - 1];
-            if (c.woodbury && !bad) {
-                // K = K0 + Q Sigma_b Q':  logdet K = logdet K0 + sum log Sigma_b + logdet M,
-                // r'K^-1 r = r'K0^-1 r - v' M^-1 v,  M = Sigma_b^-1 + Q'K0^-1 Q, v = Q'K0^-1 r   (all from W'W)
-                // (in place in the LDS copy of the Gram matrix: M(a,b) = sG[a*nrhs+b], v(a) = sG[a*nrhs+L])
-                const int Lb = c.L;
-                for (int a = 0; a < Lb; ++a) {
-                    sG[a * nrhs + a] += 1.0 / c.sigma_b[a];
-                    logdetK += log(c.sigma_b[a]);
-                }
-                for (int j = 0; j < Lb; ++j) {  // Cholesky of M + forward solve
-                    double d = sG[j * nrhs + j];
-                    for (int p2 = 0; p2 < j; ++p2) d -= sG[j * nrhs + p2] * sG[j * nrhs + p2];
-                    if (!(d > 0.0)) { bad = c.N + 1 + j; break; }
-                    d = sqrt(d);
-                    sG[j * nrhs + j] = d;
-                    for (int i = j + 1; i < Lb; ++i) {
-                        double s = sG[i * nrhs + j];
-                        for (int p2 = 0; p2 < j; ++p2) s -= sG[i * nrhs + p2] * sG[j * nrhs + p2];
-                        sG[i * nrhs + j] = s / d;
-                    }
-                    double s = sG[j * nrhs + Lb];
-                    for (int p2 = 0; p2 < j; ++p2) s -= sG[j * nrhs + p2] * sG[p2 * nrhs + Lb];
-                    s /= d;
-                    sG[j * nrhs + Lb] = s;
-                    logdetK += 2.0 * log(d);
-                    quad -= s * s;
-                }
-            }
-            g.out_loglik[g.first + m] = bad ? __builtin_nan("") : (-((double)c.N * log2pi + logdetK) / 2.0 - quad / 2.0);
+            const double llv = gpcc_loglik_from_gram(c, sG, nrhs, ld, bad);
+            g.out_loglik[g.first + m] = bad ? __builtin_nan("") : llv;
             g.out_info[g.first + m] = bad ? ((bad > c.N) ? bad : k * GPCC_TILE + bad) : 0;
         }
     }
     // ---- write inv(L_kk) (B operand of the panel solve) and L_kk, both in tile layout
-    T *Linv = (T *)c.linv + (long)slot * GPCC_TILE_ELEMS;
+    T *Linv = (T *)c.linv + gpcc_linv_off(c, slot, k);
     const bool store_l = c.store_l != 0;   // L_kk is read by nobody on the log-likelihood path (dense export only)
 #pragma unroll 4
     for (int p0 = tid; p0 < NPIECE; p0 += NT) {   // 16-byte stores; unconditional LDS reads (address select), masked after
@@ -970,6 +1042,196 @@ __global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c,
             for (int h = 0; h < P::EP; ++h) lo[h] = (T)((col0 + h <= r) ? sT[r * LD + col0 + h] : 0.0);
             *(typename P::v16 *)(Tt + e) = lo;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fp32 mode, refinement of the quadratic forms.  An fp32 factor L~ gives G~ = R' (L~ L~')^-1 R with a
+// first-order error in E = L~ L~' - K0 that dominates the error of the log-likelihood (it is 10-100x the error of
+// logdet: tr(K0^-1 E) averages out, w' E w does not).  For ANY approximate solution X ~ K0^-1 R
+//     G = R' K0^-1 R = X'R + R'X - X' K0 X + O(|X - K0^-1 R|^2)
+// so one backward solve X = L~^-T W (gpcc_back_solve) and one pass over the fp64 elements of K0, regenerated on the fly
+// exactly as the assembly computes them before rounding (gpcc_refine_partials), make G second-order accurate;
+// gpcc_refine_finish then repeats the log-likelihood arithmetic with it.  N^2 work against the N^3/3 of the factorisation.
+// ------------------------------------------------------------------------------------------
+// gpcc_back_solve: one workgroup per evaluation, X = L~^-T W in place of z (nrhs x Np, fp64).  Thread (col, grp):
+// column col of the current tile, rows grp, grp+4, ...: a transposed matrix-vector product per tile, the four row
+// groups combined through LDS.  Row r of a chunk is 128 contiguous bytes, so the 4-byte loads of 32 neighbouring
+// columns coalesce.  Streaming, one pass over the strictly lower tiles and the nt inverses inv(L_kk) (linv_keep).
+template <typename T>
+__global__ __launch_bounds__(512) void gpcc_back_solve(GpccCtx c, GpccGroup g)
+{
+    const int m = blockIdx.x, slot = g.slot0 + m, tid = threadIdx.x;
+    if (c.info[slot] != 0 || gpcc_leader_failure(c, g) != 0) return;
+    const int col = tid & 127, grp = tid >> 7, nrhs = c.nrhs;
+    __shared__ double sx[GPCC_MAXRHS][GPCC_TILE];
+    __shared__ double sp[4][GPCC_MAXRHS][GPCC_TILE];
+    double *X = c.z + (long)slot * nrhs * c.Np;
+    const double *W = c.w + (long)slot * nrhs * c.Np;
+    const int p = c.share_p;   // shared prefix: tiles, inverses and W of tile rows < p are the group leader's
+    for (int k = c.nt - 1; k >= 0; --k) {
+        const int kslot = (p && k < p) ? g.slot0 : slot;
+        double acc[GPCC_MAXRHS];
+#pragma unroll
+        for (int a = 0; a < GPCC_MAXRHS; ++a) acc[a] = 0.0;
+        for (int I = c.nt - 1; I >= k; --I) {
+            // I > k: tile L(I,k) against x_I;  I == k: inv(L_kk) against b = w_k - (what the tiles below summed to)
+            __syncthreads();
+            if (I > k) {
+                for (int e = tid; e < nrhs * GPCC_TILE; e += 512)
+                    sx[e / GPCC_TILE][e % GPCC_TILE] = X[(long)(e / GPCC_TILE) * c.Np + I * GPCC_TILE + (e % GPCC_TILE)];
+            } else {
+#pragma unroll
+                for (int a = 0; a < GPCC_MAXRHS; ++a)
+                    if (a < nrhs) sp[grp][a][col] = acc[a];
+                __syncthreads();
+                const double *Wk = c.w + (long)kslot * nrhs * c.Np;
+                for (int e = tid; e < nrhs * GPCC_TILE; e += 512) {
+                    const int a = e / GPCC_TILE, cc = e % GPCC_TILE;
+                    sx[a][cc] = Wk[(long)a * c.Np + k * GPCC_TILE + cc] - (((sp[0][a][cc] + sp[1][a][cc]) + sp[2][a][cc]) + sp[3][a][cc]);
+                }
+#pragma unroll
+                for (int a = 0; a < GPCC_MAXRHS; ++a) acc[a] = 0.0;
+            }
+            __syncthreads();
+            const int tslot = (p && I < p) ? g.slot0 : slot;   // (I < p implies k < p: the leader's tile)
+            const T *tile = (I > k) ? (const T *)c.tiles + (long)tslot * c.slot_stride + gpcc_tile_off(I, k)
+                                    : (const T *)c.linv + gpcc_linv_off(c, kslot, k);
+#pragma unroll 2
+            for (int r0 = 0; r0 < GPCC_TILE; r0 += 32) {
+                T v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = tile[gpcc_elem_off<T>(r0 + 4 * u + grp, col)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int a = 0; a < GPCC_MAXRHS; ++a)
+                        if (a < nrhs) acc[a] = fma((double)v[u], sx[a][r0 + 4 * u + grp], acc[a]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < GPCC_MAXRHS; ++a)
+            if (a < nrhs) sp[grp][a][col] = acc[a];
+        __syncthreads();
+        // (a follower of a shared prefix has its own x also on the prefix rows: they depend on its x below)
+        for (int e = tid; e < nrhs * GPCC_TILE; e += 512) {
+            const int a = e / GPCC_TILE, cc = e % GPCC_TILE;
+            X[(long)a * c.Np + k * GPCC_TILE + cc] = ((sp[0][a][cc] + sp[1][a][cc]) + sp[2][a][cc]) + sp[3][a][cc];
+        }
+    }
+}
+
+// gpcc_refine_partials: per lower tile (I,J) the contribution to X' K0 X, K0 = delayedCovariance + Sobs in fp64 exactly
+// as gpcc_assemble_tiles forms it before rounding.  Thread = one row of the tile and one half of its columns; only the
+// row sums s_a[i] = sum_j K_ij x_a[j] are needed:  off-diagonal tiles stand for (I,J) and (J,I):
+//     sum_ij K_ij (x_a[i] x_b[j] + x_a[j] x_b[i]) = sum_i (x_a[i] s_b[i] + x_b[i] s_a[i]).
+// Deterministic: fixed reduction tree, one partial per tile (no atomics).   grid (nt*nt, cnt), block 256.
+template <int KID>
+__global__ __launch_bounds__(256) void gpcc_refine_partials(GpccCtx c, GpccGroup g)
+{
+    const int I = blockIdx.x / c.nt, J = blockIdx.x % c.nt;
+    if (J > I) return;
+    const int m = blockIdx.y, slot = g.slot0 + m, tid = threadIdx.x, nrhs = c.nrhs;
+    if (c.info[slot] != 0 || gpcc_leader_failure(c, g) != 0) return;
+    const double *delays = g.delays + (long)(g.first + m) * c.L;
+    const double *alpha = g.alpha + (long)(g.first + m) * c.L;
+    const GpccKernelConst kc = gpcc_kernel_const<KID>(g.rho[g.first + m]);
+    __shared__ double su[2][GPCC_TILE], sa[2][GPCC_TILE], ssig[GPCC_TILE], sx[2][GPCC_MAXRHS][GPCC_TILE];
+    __shared__ int sb[2][GPCC_TILE];
+    __shared__ double sred[4][GPCC_MAXRHS * GPCC_MAXRHS];
+    {
+        const int side = tid >> 7, r = tid & 127;
+        const int T0 = side ? J : I, gi = T0 * GPCC_TILE + r;
+        const int b = c.band[gi];
+        sb[side][r] = b;
+        su[side][r] = (b >= 0) ? c.t[gi] - delays[b] : 0.0;
+        sa[side][r] = (b >= 0) ? alpha[b] : 0.0;
+        if (side == 0) ssig[r] = c.sig2[gi];
+        const double *X = c.z + (long)slot * nrhs * c.Np;
+        for (int a = 0; a < nrhs; ++a) sx[side][a][r] = X[(long)a * c.Np + gi];
+    }
+    __syncthreads();
+    const int i = tid & 127, half = tid >> 7;
+    const bool diag = (I == J);
+    const int br = sb[0][i];
+    const double ur = su[0][i], ar = sa[0][i], sg = ssig[i];
+    double s[GPCC_MAXRHS];
+#pragma unroll
+    for (int a = 0; a < GPCC_MAXRHS; ++a) s[a] = 0.0;
+    for (int jj = 0; jj < 64; ++jj) {
+        const int j = half * 64 + jj;
+        const int bc = sb[1][j];
+        double val = (ar * sa[1][j]) * gpcc_kernel_eval<KID>(ur, su[1][j], kc);
+        if (diag && i == j) val = val + sg;
+        if (br < 0 || bc < 0) val = 0.0;   // padding / explicit rows: X is zero there
+#pragma unroll
+        for (int a = 0; a < GPCC_MAXRHS; ++a)
+            if (a < nrhs) s[a] = fma(val, sx[1][a][j], s[a]);
+    }
+    // per-thread contribution to every (a,b), reduced over the 256 threads in a fixed order
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int a = 0; a < nrhs; ++a)
+        for (int b = 0; b < nrhs; ++b) {
+            double v = sx[0][a][i] * s[b];
+            if (!diag) v += sx[0][b][i] * s[a];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0) sred[wave][a * nrhs + b] = v;
+        }
+    __syncthreads();
+    if (tid < nrhs * nrhs) {
+        const long tidx = (long)I * (I + 1) / 2 + J, ntri = (long)c.nt * (c.nt + 1) / 2;
+        c.gpart[((long)slot * ntri + tidx) * (GPCC_MAXRHS * GPCC_MAXRHS) + tid] = ((sred[0][tid] + sred[1][tid]) + sred[2][tid]) + sred[3][tid];
+    }
+}
+
+// gpcc_refine_finish: G = X'R + R'X - X' K0 X  (R = [Q | Y - bbar] in woodbury mode, else Y - bbar), then the same
+// log-likelihood arithmetic as the last diagonal step, whose outputs it replaces.   grid cnt, block 256.
+__global__ __launch_bounds__(256) void gpcc_refine_finish(GpccCtx c, GpccGroup g)
+{
+    const int m = blockIdx.x, slot = g.slot0 + m, tid = threadIdx.x, nrhs = c.nrhs, n2 = nrhs * nrhs;
+    if (c.info[slot] != 0 || gpcc_leader_failure(c, g) != 0) return;   // the diagonal kernel has reported the failure
+    __shared__ double sacc[256];
+    __shared__ double sG[GPCC_MAXRHS * GPCC_MAXRHS], sXR[GPCC_MAXRHS * GPCC_MAXRHS];
+    const long ntri = (long)c.nt * (c.nt + 1) / 2;
+    const double *Xown = c.z + (long)slot * nrhs * c.Np;
+    for (int e = 0; e < n2; ++e) {
+        const int a = e / nrhs, b = e % nrhs;
+        double v = 0.0;   // X' K0 X: the per-tile partials, fixed order
+        for (long t = tid; t < ntri; t += 256) v += c.gpart[((long)slot * ntri + t) * (GPCC_MAXRHS * GPCC_MAXRHS) + e];
+        sacc[tid] = v;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) sacc[tid] += sacc[tid + st];
+            __syncthreads();
+        }
+        if (tid == 0) sG[e] = sacc[0];
+        __syncthreads();
+        // X'R: column b of R is the indicator of band b (woodbury, b < nrhs - 1) or the residual Y - bbar
+        v = 0.0;
+        for (int i = tid; i < c.Np; i += 256) {
+            const double xa = Xown[(long)a * c.Np + i];
+            const double rb = (b < nrhs - 1) ? ((c.band[i] == b) ? 1.0 : 0.0) : c.resid[i];
+            v = fma(xa, rb, v);
+        }
+        sacc[tid] = v;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) sacc[tid] += sacc[tid + st];
+            __syncthreads();
+        }
+        if (tid == 0) sXR[e] = sacc[0];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double G[GPCC_MAXRHS * GPCC_MAXRHS];
+        for (int a = 0; a < nrhs; ++a)
+            for (int b = 0; b < nrhs; ++b) G[a * nrhs + b] = (sXR[a * nrhs + b] + sXR[b * nrhs + a]) - 0.5 * (sG[a * nrhs + b] + sG[b * nrhs + a]);
+        int bad = 0;
+        const double llv = gpcc_loglik_from_gram(c, G, nrhs, c.logdet[slot], bad);
+        g.out_loglik[g.first + m] = bad ? __builtin_nan("") : llv;
+        g.out_info[g.first + m] = bad;
     }
 }
 

@@ -93,6 +93,18 @@ long gpcc_get_option(gpcc_handle_t handle, const char *key);
 /* mu_b[L], Sigma_b[L], resid[N] as precomputed at create (any pointer may be NULL). */
 int gpcc_get_constants(gpcc_handle_t handle, double *mean_b, double *Sigma_b, double *resid);
 
+/* fp32 handles: [sum_i K_ii / d_i, max_i K_ii / d_i] over the Cholesky pivots d_i of each of the first M evaluations
+ * of the last gpcc_loglik_batch / gpcc_loglik_batch_device call (2 M doubles) -- the conditioning measure behind the
+ * fp32 accuracy guard.  An fp32 handle (a) refines the quadratic forms r'K^-1 r, Q'K^-1 Q, Q'K^-1 r in fp64 after the
+ * fp32 factorisation (one backward solve + one pass over the fp64 elements of K regenerated on the fly: second-order
+ * accurate, N^2 work; option "fp32_refine", default 1) and (b) repeats in fp64 -- internally, on a small fp64 workspace
+ * it creates on first use -- every evaluation whose mean pivot ratio sum / N exceeds 300 (30 without refinement) or whose
+ * fp32 factorisation met a non-positive pivot, so that results stay within the 1e-3 bar of fp32 also for
+ * ill-conditioned hyper-parameters (calibration: DESIGN.md 4.7).  Options: "fp32_guard" (1 default, 0 = never repeat),
+ * "fp32_guard_count" (read-only: evaluations repeated so far).  The guard reads the estimates back, so an fp32
+ * handle synchronises the caller's stream once per call (also in the _device form). */
+int gpcc_get_conditioning(gpcc_handle_t handle, int M, double *out);
+
 /* THE HOT PATH.  objective(alpha, rho) of src/gpccfixdelay_marginaliseb.jl:133-141
  * (src/gpccfixdelay.jl:131-139 when marginalise_b == 0) for M independent (tau, alpha, rho):
  *   K = delayedCovariance(kernel, alpha, tau, rho, tarray) + Sobs + B ; logpdf(MvNormal(bbar, K), Y).
@@ -196,7 +208,8 @@ enum {
     GPCC_PROF_PANEL_UPDATE = 1, /* gpcc_panel_update       -- fp64 MFMA, dominant */
     GPCC_PROF_DIAG = 2,         /* gpcc_diag_factor */
     GPCC_PROF_TRSM = 3,         /* gpcc_panel_trsm         -- fp64 MFMA */
-    GPCC_PROF_COUNT = 4
+    GPCC_PROF_REFINE = 4,       /* fp32 mode: backward solve + X' K0 X + final arithmetic */
+    GPCC_PROF_COUNT = 5
 };
 int gpcc_profile_enable(gpcc_handle_t handle, int on);
 int gpcc_profile_reset(gpcc_handle_t handle);

@@ -35,9 +35,9 @@ while time.time() < t_end:
     s = [rng.uniform(0.05, 1.0, n) for n in Nl]
     kname = knames[int(rng.integers(0, 4))]
     prec = "fp32" if rng.random() < 0.4 else "fp64"
-    # fp32: 1e-3 is the bar on the benchmark data (sigma = 0.75); here sigma goes down to 0.05 and alpha up to 5, and the
-    # error of an fp32 factorisation grows with the condition number -- count the excursions, fail only beyond 5e-3
-    tol = 5e-3 if prec == "fp32" else 1e-9
+    # fp32: the 1e-3 bar of BASELINE north_star holds everywhere -- ill-conditioned evaluations (sigma goes down to 0.05
+    # here, alpha up to 5) are repeated in fp64 by the handle's accuracy guard
+    tol = 1e-3 if prec == "fp32" else 1e-9
     M = int(rng.choice([1, 5, 40, 130, 300])) if BIG else int(rng.choice([1, 2, 5, 7, 8, 9, 24, 25, 33, 70]))
     delays = rng.uniform(-5, 20, (M, L))
     alpha = 10.0 ** rng.uniform(-0.7, 0.7, (M, L))
