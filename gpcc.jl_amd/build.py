@@ -40,17 +40,16 @@ def build(force=False, verbose=False):
 
 
 def ensure_present(local_rank=0, timeout_s=900.0):
-    """For launchers that start one process per GPU from a source-only checkout: local rank 0 compiles the
-    library if the file is absent, the other ranks wait for it to appear.  Never rebuilds an existing file."""
+    """For launchers that start one process per GPU: local rank 0 (re)builds the library when it is missing OR older
+    than its sources (the same mtime check as build()), the other ranks wait until an up-to-date file is there --
+    so a benchmark never times a stale library after an edit of csrc/."""
     import time
-    if os.path.exists(LIB_PATH):
-        return LIB_PATH
     if local_rank == 0:
-        return build(force=True)
+        return build(force=False)
     t0 = time.time()
-    while not os.path.exists(LIB_PATH):
+    while _stale():
         if time.time() - t0 > timeout_s:
-            raise RuntimeError("%s did not appear within %.0f s" % (LIB_PATH, timeout_s))
+            raise RuntimeError("%s did not become current within %.0f s" % (LIB_PATH, timeout_s))
         time.sleep(1.0)
     return LIB_PATH
 
