@@ -36,6 +36,7 @@ struct gpcc_handle_s {
     std::vector<int> band_host;
     // options
     int streams = 1, slots_per_stream = 256, right_looking_max = GPCC_RIGHT_LOOKING_MAX;
+    int fused_small_max = 4;   // groups of at most this many evaluations run gpcc_small_step (update + next diagonal step in one launch)
     int shared_prefix = 1;   // 0 off, 1 auto (host-pointer API detects it), 2 the caller asserts it
     int share_tiles = 0;     // tile rows wholly inside band 1
     bool share_now = false;  // decision for the batch being enqueued
@@ -305,6 +306,8 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->slots_per_stream = (int)v;
     } else if (!strcmp(key, "right_looking_max")) {
         h->right_looking_max = (int)v;
+    } else if (!strcmp(key, "fused_small_max")) {
+        h->fused_small_max = (int)v;
     } else if (!strcmp(key, "fp32_guard")) {
         h->fp32_guard = v != 0;
     } else if (!strcmp(key, "fp32_refine")) {
@@ -327,6 +330,7 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "streams")) return h->streams;
     if (!strcmp(key, "slots_per_stream")) return h->slots_per_stream;
     if (!strcmp(key, "right_looking_max")) return h->right_looking_max;
+    if (!strcmp(key, "fused_small_max")) return h->fused_small_max;
     if (!strcmp(key, "shared_prefix")) return h->shared_prefix;
     if (!strcmp(key, "share_tiles")) return h->share_tiles;
     if (!strcmp(key, "N")) return h->N;
@@ -364,6 +368,8 @@ static int set_kernel_attributes(gpcc_handle_t h)
 {
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_diag_factor<double>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_DIAG_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_diag_factor<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_DIAG_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_small_step<double>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_DIAG_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_small_step<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_DIAG_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<double, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<double, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
@@ -490,6 +496,24 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
     // small groups (the single objective(alpha, rho) call): right-looking, many short jobs per step
     const bool right = (g.cnt <= h->right_looking_max) && (c.nt_fact == c.nt) && !c.share_p;
     const int p = c.share_p;   // shared prefix: steps k < p only involve the leader's rows < p and everyone's rows >= p
+    if (right && g.cnt <= h->fused_small_max && c.nt > 1) {
+        // a few evaluations (the objective(alpha, rho) call site): diag(0), then per step the panel solve and ONE launch
+        // that holds the trailing update of step k AND the diagonal step k+1 (gpcc_small_step): 2 nt - 1 launches
+        {
+            ProfScope pr(h, GPCC_PROF_DIAG, s);
+            gpcc_diag_factor<T><<<g.cnt, GPCC_DIAG_THREADS, GPCC_DIAG_LDS_BYTES, s>>>(c, g, 0);
+        }
+        for (int k = 0; k < c.nt - 1; ++k) {
+            {
+                ProfScope pr(h, GPCC_PROF_TRSM, s);
+                gpcc_panel_trsm<T><<<cnt8 * (c.nt - k - 1), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
+            }
+            ProfScope pr(h, GPCC_PROF_SMALL_STEP, s);
+            const int n = c.nt - k - 1;
+            gpcc_small_step<T><<<g.cnt * (n * (n + 1) / 2), 512, GPCC_DIAG_LDS_BYTES, s>>>(c, g, k);
+        }
+        return;
+    }
     for (int k = 0; k < c.nt_fact; ++k) {
         if (k > 0 && !right) {
             ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);

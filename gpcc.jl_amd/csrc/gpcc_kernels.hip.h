@@ -672,12 +672,12 @@ __device__ __forceinline__ double gpcc_loglik_from_gram(const GpccCtx &c, double
             return -((double)c.N * log2pi + logdetK) / 2.0 - quad / 2.0;
 }
 
-template <typename T>
-__global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c, GpccGroup g, int k)
+// PRELOADED: the caller (gpcc_small_step) has already put the updated tile into sT (fp64 image of the values of type T).
+template <typename T, bool PRELOADED>
+__device__ __forceinline__ void gpcc_diag_body(const GpccCtx &c, const GpccGroup &g, const int k, const int m, double *smem)
 {
     typedef GpccPrec<T> P;
     typedef GpccPrec<double> PD;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int LD = GPCC_DIAG_LD, DLD = GPCC_DINV_LD;
     double *sT = smem;                          // 128 x LD: lower = A -> L ; upper = inv(L)^T off-diagonal blocks
     double *sDinv = sT + GPCC_TILE * LD;        // 8 x 16 x DLD: inverses X_b of the 16x16 diagonal blocks, TRANSPOSED:
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c,
     // way; the other six are the MFMA workers of (C), (X), (W).
     constexpr int NWK = 6;
     const int wk = (wave == 0 || wave == 4) ? -1 : (wave < 4 ? wave - 1 : wave - 2);
-    const int m = blockIdx.x, slot = g.slot0 + m, nrhs = c.nrhs;
+    const int slot = g.slot0 + m, nrhs = c.nrhs;
     const bool last = (k == c.nt_fact - 1);
     int inf = c.info[slot];
     if (inf == 0 && m > 0) inf = gpcc_leader_failure(c, g);   // a failed shared prefix fails its followers too
@@ -714,6 +714,7 @@ __global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c,
     constexpr int NT = GPCC_DIAG_THREADS;
     constexpr int UL = (NPIECE / NT < 16) ? NPIECE / NT : 16;   // loads in flight per thread (fp64: 16, fp32: 8)
     static_assert(NPIECE % (NT * UL) == 0, "tile pieces must divide evenly over the threads");
+    if (!PRELOADED)
     for (int p0 = tid; p0 < NPIECE; p0 += NT * UL) {
         typename P::v16 v[UL];
 #pragma unroll
@@ -1043,6 +1044,111 @@ __global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c,
             *(typename P::v16 *)(Tt + e) = lo;
         }
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c, GpccGroup g, int k)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    gpcc_diag_body<T, false>(c, g, k, blockIdx.x, smem);
+}
+
+// ------------------------------------------------------------------------------------------
+// gpcc_small_step (step k of a group of a FEW evaluations, e.g. the single objective(alpha, rho) of Nelder-Mead): the
+// right-looking trailing update T(I,J) -= L(I,k) L(J,k)^T for every tile k < J <= I, and -- in the workgroup that owns
+// tile (k+1,k+1) -- straight on into gpcc_diag_body of step k+1 with the updated tile handed over in LDS (no global round
+// trip, no launch in between).  One evaluation's critical path is diag -> solve -> update of ONE tile -> diag ...; with
+// the diagonal step inside the update launch the rest of the trailing update runs beside it instead of before it:
+// launches per evaluation 3 nt - 2 -> 2 nt - 1.   grid cnt * n(n+1)/2 (n = nt-k-1), block 512, LDS = the diagonal image.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(512) void gpcc_small_step(GpccCtx c, GpccGroup g, int k)
+{
+    typedef GpccPrec<T> P;
+    constexpr int CH = GPCC_CHUNK_BYTES / sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) double smem_d[];
+    T *smem = (T *)smem_d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, q = lane >> 4;
+    const int sw = gpcc_sw(lr);
+    const int m = (int)blockIdx.x % g.cnt, j = (int)blockIdx.x / g.cnt;   // job j of evaluation m; j = 0 is tile (k+1,k+1)
+    const int slot = g.slot0 + m;
+    if (c.info[slot] != 0) {
+        if (j == 0) gpcc_diag_body<T, true>(c, g, k + 1, m, smem_d);   // (reports the failure on the last step, touches no LDS)
+        return;
+    }
+    int a = (int)((sqrtf(8.0f * j + 1.0f) - 1.0f) * 0.5f);
+    while (a * (a + 1) / 2 > j) --a;
+    while ((a + 1) * (a + 2) / 2 <= j) ++a;
+    const int I = k + 1 + a, J = k + 1 + (j - a * (a + 1) / 2);
+    T *tiles = (T *)c.tiles + (long)slot * c.slot_stride;
+    const T *gA = tiles + gpcc_tile_off(I, k), *gB = tiles + gpcc_tile_off(J, k);
+    T *Tt = tiles + gpcc_tile_off(I, J);
+    gpcc_dma_chunk<T>(gA, gB, smem, wave, lane);
+    typename P::acc_t acc[2][4];
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[fm][fn][r] = -Tt[gpcc_elem_off<T>(wr * 32 + fm * 16 + P::crow(q, r), wc * 64 + fn * 16 + lr)];
+    const T *pa0 = smem + (wr * 32 + lr) * P::KC + (((2 * q) ^ sw) * P::EP);
+    const T *pa1 = smem + (wr * 32 + lr) * P::KC + (((2 * q + 1) ^ sw) * P::EP);
+    const T *pb0 = smem + CH + (wc * 64 + lr) * P::KC + (((2 * q) ^ sw) * P::EP);
+    const T *pb1 = smem + CH + (wc * 64 + lr) * P::KC + (((2 * q + 1) ^ sw) * P::EP);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 2
+    for (int ch = 0; ch < P::NCH; ++ch) {   // one tile of K: the chunks of L(I,k) and L(J,k)
+        const int st = ch & 1;
+        if (ch + 1 < P::NCH)
+            gpcc_dma_chunk<T>(gA + (long)(ch + 1) * CH, gB + (long)(ch + 1) * CH, smem + (st ^ 1) * 2 * CH, wave, lane);
+        const int so = st * 2 * CH;
+        typename P::v16 av[2][2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            av[f][0] = *(const typename P::v16 *)(pa0 + so + f * 16 * P::KC);
+            av[f][1] = *(const typename P::v16 *)(pa1 + so + f * 16 * P::KC);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            typename P::v16 b[2][2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                b[f][0] = *(const typename P::v16 *)(pb0 + so + (2 * h + f) * 16 * P::KC);
+                b[f][1] = *(const typename P::v16 *)(pb1 + so + (2 * h + f) * 16 * P::KC);
+            }
+#pragma unroll
+            for (int s = 0; s < P::KSTEPS; ++s)
+#pragma unroll
+                for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+                        acc[fm][2 * h + f] = P::mfma(av[fm][s / P::EP][s % P::EP], b[f][s / P::EP][s % P::EP], acc[fm][2 * h + f]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (j != 0) {
+#pragma unroll
+        for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Tt[gpcc_elem_off<T>(wr * 32 + fm * 16 + P::crow(q, r), wc * 64 + fn * 16 + lr)] = -acc[fm][fn][r];
+        return;
+    }
+    // tile (k+1,k+1): hand the updated values (rounded to T, as the unfused path stores them) over to the diagonal step
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                smem_d[(wr * 32 + fm * 16 + P::crow(q, r)) * GPCC_DIAG_LD + wc * 64 + fn * 16 + lr] = (double)(T)(-acc[fm][fn][r]);
+    gpcc_diag_body<T, true>(c, g, k + 1, m, smem_d);
 }
 
 // ------------------------------------------------------------------------------------------

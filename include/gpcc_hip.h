@@ -81,7 +81,9 @@ int gpcc_multi_gathered(gpcc_handle_t handle, int which, long *blk_out, double *
 /* Tunables: "streams" (groups in flight on separate HIP streams, default 1), "slots_per_stream"
  * (evaluations resident per group, default 256 = one diagonal-block workgroup per CU, capped so
  * the workspace stays under 64 GiB), "right_looking_max" (groups of at most this many evaluations use
- * the right-looking update, default 24), "shared_prefix" (0 off; 1 = default: gpcc_loglik_batch detects a
+ * the right-looking update, default 24), "fused_small_max" (groups of at most this many evaluations, default 4, run the
+ * trailing update of a step and the next diagonal step in ONE launch: the latency path of a single objective(alpha, rho)),
+ * "shared_prefix" (0 off; 1 = default: gpcc_loglik_batch detects a
  * batch whose evaluations all have the same band-1 amplitude, delay and rho -- a fixed-hyper-parameter delay
  * sweep, README.md:172-174 -- and then factorises the tile rows wholly inside band 1 once per group instead of
  * once per evaluation, results bitwise identical; 2 = the caller asserts that property, also for the _device
@@ -209,7 +211,8 @@ enum {
     GPCC_PROF_DIAG = 2,         /* gpcc_diag_factor */
     GPCC_PROF_TRSM = 3,         /* gpcc_panel_trsm         -- fp64 MFMA */
     GPCC_PROF_REFINE = 4,       /* fp32 mode: backward solve + X' K0 X + final arithmetic */
-    GPCC_PROF_COUNT = 5
+    GPCC_PROF_SMALL_STEP = 5,   /* gpcc_small_step: trailing update + next diagonal step in one launch (a few evaluations) */
+    GPCC_PROF_COUNT = 6
 };
 int gpcc_profile_enable(gpcc_handle_t handle, int on);
 int gpcc_profile_reset(gpcc_handle_t handle);

@@ -75,11 +75,18 @@ def main():
     oracle.build()
     delays = [list(map(float, d)) for d in json.loads(args.delays)]
     cores = len(os.sched_getaffinity(0))
+    quota = None   # a container's CPU share (cgroup v2): the affinity mask of a GPU box shows every core of the host
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(round(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
     t, y, s, alpha, rho = _problem(args.n_per_band, args.bands, args.seed)
-    out = {"cores_available": cores}
+    out = {"cores_available": cores, "cgroup_cpu_quota": quota}
 
     # shape "blas": one evaluation at a time, BLAS on P threads
-    P = args.workers or cores
+    P = args.workers or min(cores, quota or 16)
     with threadpool_limits(limits=P):
         loglik_lapack(args.kernel, t, y, s, np.asarray(delays[0]), alpha, rho)   # warm-up (page-in, thread pool)
         n = min(args.blas_evals, len(delays))
@@ -88,11 +95,12 @@ def main():
         dt = time.perf_counter() - t0
     out["blas"] = {"threads": P, "evals": n, "seconds": round(dt, 3), "evals_per_s": round(n / dt, 3)}
 
-    # shape "pmap": P single-threaded workers; tried with every core and with 16 (a 1-GPU box's CPU share)
+    # shape "pmap": P single-threaded workers; P = the CPU share (cgroup quota, else 16: a 1-GPU box's share) and, where the
+    # mask shows more cores, a second run with up to 64 workers and a third of the evaluations each (bounded time)
     import multiprocessing as mp
     best = None
-    for Pw in sorted({P, min(P, 16)}, reverse=True):
-        want = Pw * args.evals_per_worker
+    for Pw in sorted({P, P if args.workers else min(cores, 64)}):
+        want = Pw * (args.evals_per_worker if Pw == P else max(1, args.evals_per_worker // 3))
         sample = (delays * (-(-want // len(delays))))[:want]
         with mp.get_context("fork").Pool(Pw, initializer=_init_worker,
                                          initargs=(args.n_per_band, args.bands, args.seed, args.kernel)) as pool:
