@@ -1160,71 +1160,116 @@ __global__ __launch_bounds__(512) void gpcc_small_step(GpccCtx c, GpccGroup g, i
 // exactly as the assembly computes them before rounding (gpcc_refine_partials), make G second-order accurate;
 // gpcc_refine_finish then repeats the log-likelihood arithmetic with it.  N^2 work against the N^3/3 of the factorisation.
 // ------------------------------------------------------------------------------------------
-// gpcc_back_solve: one workgroup per evaluation, X = L~^-T W in place of z (nrhs x Np, fp64).  Thread (col, grp):
-// column col of the current tile, rows grp, grp+4, ...: a transposed matrix-vector product per tile, the four row
-// groups combined through LDS.  Row r of a chunk is 128 contiguous bytes, so the 4-byte loads of 32 neighbouring
-// columns coalesce.  Streaming, one pass over the strictly lower tiles and the nt inverses inv(L_kk) (linv_keep).
+// gpcc_back_solve: one workgroup per evaluation, X = L~^-T W in place of z (nrhs x Np, fp64), three right-hand sides per
+// pass.  A transposed matrix-vector product per tile: thread (ls, rg) owns the 16-byte slot ls (4 columns) of rows rg,
+// rg+16, ...; eight 16-byte loads per thread in flight (64 KiB per CU: the kernel is one latency-bound stream per
+// evaluation), the 16 row groups combined by one shuffle and through LDS.  One pass over the strictly lower tiles and the nt
+// inverses inv(L_kk) (linv_keep).  fp32 tiles only.
 template <typename T>
 __global__ __launch_bounds__(512) void gpcc_back_solve(GpccCtx c, GpccGroup g)
 {
+    static_assert(sizeof(T) == 4, "the refinement exists for the fp32 mode only");
+    constexpr int RB = 3;   // right-hand sides per pass (woodbury with 2 bands: [Q | r] = 3)
     const int m = blockIdx.x, slot = g.slot0 + m, tid = threadIdx.x;
     if (c.info[slot] != 0 || gpcc_leader_failure(c, g) != 0) return;
-    const int col = tid & 127, grp = tid >> 7, nrhs = c.nrhs;
-    __shared__ double sx[GPCC_MAXRHS][GPCC_TILE];
-    __shared__ double sp[4][GPCC_MAXRHS][GPCC_TILE];
+    const int ls = tid & 31, rg = tid >> 5, wave = tid >> 6, nrhs = c.nrhs;
+    const int col0 = (ls >> 3) * 32 + (ls & 7) * 4;   // the 4 logical columns of slot ls
+    __shared__ double sx[RB][GPCC_TILE];
+    __shared__ double sp[8][RB][GPCC_TILE];
     double *X = c.z + (long)slot * nrhs * c.Np;
-    const double *W = c.w + (long)slot * nrhs * c.Np;
     const int p = c.share_p;   // shared prefix: tiles, inverses and W of tile rows < p are the group leader's
-    for (int k = c.nt - 1; k >= 0; --k) {
-        const int kslot = (p && k < p) ? g.slot0 : slot;
-        double acc[GPCC_MAXRHS];
+    for (int a0 = 0; a0 < nrhs; a0 += RB) {
+        const int na = (nrhs - a0 < RB) ? nrhs - a0 : RB;
+        for (int k = c.nt - 1; k >= 0; --k) {
+            const int kslot = (p && k < p) ? g.slot0 : slot;
+            double acc[RB][4];
 #pragma unroll
-        for (int a = 0; a < GPCC_MAXRHS; ++a) acc[a] = 0.0;
-        for (int I = c.nt - 1; I >= k; --I) {
-            // I > k: tile L(I,k) against x_I;  I == k: inv(L_kk) against b = w_k - (what the tiles below summed to)
-            __syncthreads();
-            if (I > k) {
-                for (int e = tid; e < nrhs * GPCC_TILE; e += 512)
-                    sx[e / GPCC_TILE][e % GPCC_TILE] = X[(long)(e / GPCC_TILE) * c.Np + I * GPCC_TILE + (e % GPCC_TILE)];
-            } else {
+            for (int a = 0; a < RB; ++a)
 #pragma unroll
-                for (int a = 0; a < GPCC_MAXRHS; ++a)
-                    if (a < nrhs) sp[grp][a][col] = acc[a];
-                __syncthreads();
-                const double *Wk = c.w + (long)kslot * nrhs * c.Np;
-                for (int e = tid; e < nrhs * GPCC_TILE; e += 512) {
-                    const int a = e / GPCC_TILE, cc = e % GPCC_TILE;
-                    sx[a][cc] = Wk[(long)a * c.Np + k * GPCC_TILE + cc] - (((sp[0][a][cc] + sp[1][a][cc]) + sp[2][a][cc]) + sp[3][a][cc]);
+                for (int h = 0; h < 4; ++h) acc[a][h] = 0.0;
+            // the tile stream does not depend on x: the loads of the next tile are issued before this one's arithmetic
+            auto tile_ptr = [&](int I) -> const T * {
+                const int tslot = (p && I < p) ? g.slot0 : slot;   // (I < p implies k < p: the leader's tile)
+                const T *tile = (I > k) ? (const T *)c.tiles + (long)tslot * c.slot_stride + gpcc_tile_off(I, k)
+                                        : (const T *)c.linv + gpcc_linv_off(c, kslot, k);
+                return tile + (ls >> 3) * (GPCC_TILE * 32);
+            };
+            f4 v[8], vn[8];
+            {
+                const T *base = tile_ptr(c.nt - 1);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = rg + 16 * u;
+                    vn[u] = *(const f4 *)(base + r * 32 + (((ls & 7) ^ gpcc_sw(r)) * 4));
                 }
-#pragma unroll
-                for (int a = 0; a < GPCC_MAXRHS; ++a) acc[a] = 0.0;
             }
-            __syncthreads();
-            const int tslot = (p && I < p) ? g.slot0 : slot;   // (I < p implies k < p: the leader's tile)
-            const T *tile = (I > k) ? (const T *)c.tiles + (long)tslot * c.slot_stride + gpcc_tile_off(I, k)
-                                    : (const T *)c.linv + gpcc_linv_off(c, kslot, k);
-#pragma unroll 2
-            for (int r0 = 0; r0 < GPCC_TILE; r0 += 32) {
-                T v[8];
+            for (int I = c.nt - 1; I >= k; --I) {
+                // I > k: tile L(I,k) against x_I;  I == k: inv(L_kk) against b = w_k - (what the tiles below summed to)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = tile[gpcc_elem_off<T>(r0 + 4 * u + grp, col)];
+                for (int u = 0; u < 8; ++u) v[u] = vn[u];
+                if (I > k) {
+                    const T *base = tile_ptr(I - 1);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int r = rg + 16 * u;
+                        vn[u] = *(const f4 *)(base + r * 32 + (((ls & 7) ^ gpcc_sw(r)) * 4));
+                    }
+                }
+                __syncthreads();
+                if (I > k) {
+                    for (int e = tid; e < na * GPCC_TILE; e += 512)
+                        sx[e / GPCC_TILE][e % GPCC_TILE] = X[(long)(a0 + e / GPCC_TILE) * c.Np + I * GPCC_TILE + (e % GPCC_TILE)];
+                } else {
+#pragma unroll
+                    for (int a = 0; a < RB; ++a)
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) {
+                            double vv = acc[a][h];
+                            vv += __shfl_xor(vv, 32);   // the wave's two row groups
+                            if ((tid & 32) == 0) sp[wave][a][col0 + h] = vv;
+                            acc[a][h] = 0.0;
+                        }
+                    __syncthreads();
+                    const double *Wk = c.w + (long)kslot * nrhs * c.Np;
+                    for (int e = tid; e < na * GPCC_TILE; e += 512) {
+                        const int a = e / GPCC_TILE, cc = e % GPCC_TILE;
+                        double sum = 0.0;
+#pragma unroll
+                        for (int w8 = 0; w8 < 8; ++w8) sum += sp[w8][a][cc];
+                        sx[a][cc] = Wk[(long)(a0 + a) * c.Np + k * GPCC_TILE + cc] - sum;
+                    }
+                }
+                __syncthreads();
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
 #pragma unroll
-                    for (int a = 0; a < GPCC_MAXRHS; ++a)
-                        if (a < nrhs) acc[a] = fma((double)v[u], sx[a][r0 + 4 * u + grp], acc[a]);
+                    for (int a = 0; a < RB; ++a)
+                        if (a < na) {
+                            const double xv = sx[a][rg + 16 * u];
+#pragma unroll
+                            for (int h = 0; h < 4; ++h) acc[a][h] = fma((double)v[u][h], xv, acc[a][h]);
+                        }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < RB; ++a)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    double v = acc[a][h];
+                    v += __shfl_xor(v, 32);
+                    if ((tid & 32) == 0) sp[wave][a][col0 + h] = v;
+                }
+            __syncthreads();
+            // (a follower of a shared prefix has its own x also on the prefix rows: they depend on its x below)
+            for (int e = tid; e < na * GPCC_TILE; e += 512) {
+                const int a = e / GPCC_TILE, cc = e % GPCC_TILE;
+                double sum = 0.0;
+#pragma unroll
+                for (int w8 = 0; w8 < 8; ++w8) sum += sp[w8][a][cc];
+                X[(long)(a0 + a) * c.Np + k * GPCC_TILE + cc] = sum;
             }
         }
         __syncthreads();
-#pragma unroll
-        for (int a = 0; a < GPCC_MAXRHS; ++a)
-            if (a < nrhs) sp[grp][a][col] = acc[a];
-        __syncthreads();
-        // (a follower of a shared prefix has its own x also on the prefix rows: they depend on its x below)
-        for (int e = tid; e < nrhs * GPCC_TILE; e += 512) {
-            const int a = e / GPCC_TILE, cc = e % GPCC_TILE;
-            X[(long)a * c.Np + k * GPCC_TILE + cc] = ((sp[0][a][cc] + sp[1][a][cc]) + sp[2][a][cc]) + sp[3][a][cc];
-        }
     }
 }
 
@@ -1265,15 +1310,29 @@ __global__ __launch_bounds__(256) void gpcc_refine_partials(GpccCtx c, GpccGroup
     double s[GPCC_MAXRHS];
 #pragma unroll
     for (int a = 0; a < GPCC_MAXRHS; ++a) s[a] = 0.0;
-    for (int jj = 0; jj < 64; ++jj) {
-        const int j = half * 64 + jj;
-        const int bc = sb[1][j];
-        double val = (ar * sa[1][j]) * gpcc_kernel_eval<KID>(ur, su[1][j], kc);
-        if (diag && i == j) val = val + sg;
-        if (br < 0 || bc < 0) val = 0.0;   // padding / explicit rows: X is zero there
+    // tiles inside one band pair and off the diagonal (most of them: points are ordered by band): no selects
+    const bool plain = !diag && sb[0][0] >= 0 && sb[1][0] >= 0 && sb[0][0] == sb[0][GPCC_TILE - 1] && sb[1][0] == sb[1][GPCC_TILE - 1];
+    if (plain) {
+#pragma unroll 4
+        for (int jj = 0; jj < 64; ++jj) {
+            const int j = half * 64 + jj;
+            const double val = (ar * sa[1][j]) * gpcc_kernel_eval<KID>(ur, su[1][j], kc);
 #pragma unroll
-        for (int a = 0; a < GPCC_MAXRHS; ++a)
-            if (a < nrhs) s[a] = fma(val, sx[1][a][j], s[a]);
+            for (int a = 0; a < GPCC_MAXRHS; ++a)
+                if (a < nrhs) s[a] = fma(val, sx[1][a][j], s[a]);
+        }
+    } else {
+#pragma unroll 4
+        for (int jj = 0; jj < 64; ++jj) {
+            const int j = half * 64 + jj;
+            const int bc = sb[1][j];
+            double val = (ar * sa[1][j]) * gpcc_kernel_eval<KID>(ur, su[1][j], kc);
+            if (diag && i == j) val = val + sg;
+            if (br < 0 || bc < 0) val = 0.0;   // padding / explicit rows: X is zero there
+#pragma unroll
+            for (int a = 0; a < GPCC_MAXRHS; ++a)
+                if (a < nrhs) s[a] = fma(val, sx[1][a][j], s[a]);
+        }
     }
     // per-thread contribution to every (a,b), reduced over the 256 threads in a fixed order
     const int lane = tid & 63, wave = tid >> 6;
