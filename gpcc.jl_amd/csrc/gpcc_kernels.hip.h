@@ -1053,6 +1053,62 @@ __global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c,
     gpcc_diag_body<T, false>(c, g, k, blockIdx.x, smem);
 }
 
+// The tile (k+1,k+1) of gpcc_small_step sits on the critical path of a single evaluation (update -> diagonal step ->
+// panel solve -> update ...) and the diagonal step only reads its lower triangle: 36 of the 64 16x16 blocks, dealt
+// 5/5/5/5/4/4/4/4 to the eight waves (waves w and w+4 share a SIMD: one 5-block and one 4-block wave each) -- 56 % of the
+// MFMA time of the full tile.  Wave-specialised: NA blocks (RA, CA..CA+NA-1) and NB blocks (RB, CB..CB+NB-1).
+template <typename T, int RA, int CA, int NA, int RB, int CB, int NB>
+__device__ __forceinline__ void gpcc_small_diag_tile(const T *gA, const T *gB, T *smem, const T *Tt, double *smem_d, int wave, int lane)
+{
+    typedef GpccPrec<T> P;
+    constexpr int CH = GPCC_CHUNK_BYTES / sizeof(T);
+    const int lr = lane & 15, q = lane >> 4, sw = gpcc_sw(lr);
+    typename P::acc_t acc[NA + NB];
+#pragma unroll
+    for (int i = 0; i < NA + NB; ++i) {
+        const int R = (i < NA) ? RA : RB, C = (i < NA) ? CA + i : CB + (i - NA);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] = -Tt[gpcc_elem_off<T>(16 * R + P::crow(q, r), 16 * C + lr)];
+    }
+    const T *p0 = smem + lr * P::KC + (((2 * q) ^ sw) * P::EP);       // row lr of a 16-row fragment, slots 2q / 2q+1
+    const T *p1 = smem + lr * P::KC + (((2 * q + 1) ^ sw) * P::EP);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 2
+    for (int ch = 0; ch < P::NCH; ++ch) {
+        const int st = ch & 1;
+        if (ch + 1 < P::NCH)
+            gpcc_dma_chunk<T>(gA + (long)(ch + 1) * CH, gB + (long)(ch + 1) * CH, smem + (st ^ 1) * 2 * CH, wave, lane);
+        const int so = st * 2 * CH;
+        typename P::v16 aA[2], aB[2];
+        aA[0] = *(const typename P::v16 *)(p0 + so + RA * 16 * P::KC);
+        aA[1] = *(const typename P::v16 *)(p1 + so + RA * 16 * P::KC);
+        if (NB > 0) {
+            aB[0] = *(const typename P::v16 *)(p0 + so + RB * 16 * P::KC);
+            aB[1] = *(const typename P::v16 *)(p1 + so + RB * 16 * P::KC);
+        }
+#pragma unroll
+        for (int i = 0; i < NA + NB; ++i) {
+            const int C = (i < NA) ? CA + i : CB + (i - NA);
+            typename P::v16 b[2];
+            b[0] = *(const typename P::v16 *)(p0 + so + CH + C * 16 * P::KC);
+            b[1] = *(const typename P::v16 *)(p1 + so + CH + C * 16 * P::KC);
+#pragma unroll
+            for (int s = 0; s < P::KSTEPS; ++s)
+                acc[i] = P::mfma((i < NA) ? aA[s / P::EP][s % P::EP] : aB[s / P::EP][s % P::EP], b[s / P::EP][s % P::EP], acc[i]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // hand the updated blocks (rounded to T, as the unfused path stores them) over to the diagonal step's LDS image
+#pragma unroll
+    for (int i = 0; i < NA + NB; ++i) {
+        const int R = (i < NA) ? RA : RB, C = (i < NA) ? CA + i : CB + (i - NA);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) smem_d[(16 * R + P::crow(q, r)) * GPCC_DIAG_LD + 16 * C + lr] = (double)(T)(-acc[i][r]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // gpcc_small_step (step k of a group of a FEW evaluations, e.g. the single objective(alpha, rho) of Nelder-Mead): the
 // right-looking trailing update T(I,J) -= L(I,k) L(J,k)^T for every tile k < J <= I, and -- in the workgroup that owns
@@ -1085,6 +1141,20 @@ __global__ __launch_bounds__(512) void gpcc_small_step(GpccCtx c, GpccGroup g, i
     const T *gA = tiles + gpcc_tile_off(I, k), *gB = tiles + gpcc_tile_off(J, k);
     T *Tt = tiles + gpcc_tile_off(I, J);
     gpcc_dma_chunk<T>(gA, gB, smem, wave, lane);
+    if (j == 0) {   // tile (k+1,k+1): lower triangle only, then straight on into the diagonal step
+        switch (__builtin_amdgcn_readfirstlane(wave)) {
+        case 0: gpcc_small_diag_tile<T, 7, 0, 5, 0, 0, 0>(gA, gB, smem, Tt, smem_d, wave, lane); break;
+        case 1: gpcc_small_diag_tile<T, 6, 0, 5, 0, 0, 0>(gA, gB, smem, Tt, smem_d, wave, lane); break;
+        case 2: gpcc_small_diag_tile<T, 5, 0, 5, 0, 0, 0>(gA, gB, smem, Tt, smem_d, wave, lane); break;
+        case 3: gpcc_small_diag_tile<T, 4, 0, 5, 0, 0, 0>(gA, gB, smem, Tt, smem_d, wave, lane); break;
+        case 4: gpcc_small_diag_tile<T, 7, 5, 3, 0, 0, 1>(gA, gB, smem, Tt, smem_d, wave, lane); break;
+        case 5: gpcc_small_diag_tile<T, 6, 5, 2, 1, 0, 2>(gA, gB, smem, Tt, smem_d, wave, lane); break;
+        case 6: gpcc_small_diag_tile<T, 5, 5, 1, 2, 0, 3>(gA, gB, smem, Tt, smem_d, wave, lane); break;
+        default: gpcc_small_diag_tile<T, 3, 0, 4, 0, 0, 0>(gA, gB, smem, Tt, smem_d, wave, lane); break;
+        }
+        gpcc_diag_body<T, true>(c, g, k + 1, m, smem_d);
+        return;
+    }
     typename P::acc_t acc[2][4];
 #pragma unroll
     for (int fm = 0; fm < 2; ++fm)
@@ -1130,25 +1200,13 @@ __global__ __launch_bounds__(512) void gpcc_small_step(GpccCtx c, GpccGroup g, i
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if (j != 0) {
-#pragma unroll
-        for (int fm = 0; fm < 2; ++fm)
-#pragma unroll
-            for (int fn = 0; fn < 4; ++fn)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    Tt[gpcc_elem_off<T>(wr * 32 + fm * 16 + P::crow(q, r), wc * 64 + fn * 16 + lr)] = -acc[fm][fn][r];
-        return;
-    }
-    // tile (k+1,k+1): hand the updated values (rounded to T, as the unfused path stores them) over to the diagonal step
 #pragma unroll
     for (int fm = 0; fm < 2; ++fm)
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                smem_d[(wr * 32 + fm * 16 + P::crow(q, r)) * GPCC_DIAG_LD + wc * 64 + fn * 16 + lr] = (double)(T)(-acc[fm][fn][r]);
-    gpcc_diag_body<T, true>(c, g, k + 1, m, smem_d);
+                Tt[gpcc_elem_off<T>(wr * 32 + fm * 16 + P::crow(q, r), wc * 64 + fn * 16 + lr)] = -acc[fm][fn][r];
 }
 
 // ------------------------------------------------------------------------------------------
