@@ -376,6 +376,8 @@ static int set_kernel_attributes(gpcc_handle_t h)
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_trsm<double>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_trsm<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_trsm_rows<double>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_TRSM_ROWS_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_trsm_rows<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_TRSM_ROWS_LDS_BYTES));
     return 0;
 }
 
@@ -506,7 +508,7 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
         for (int k = 0; k < c.nt - 1; ++k) {
             {
                 ProfScope pr(h, GPCC_PROF_TRSM, s);
-                gpcc_panel_trsm<T><<<cnt8 * (c.nt - k - 1), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
+                gpcc_panel_trsm_rows<T><<<g.cnt * (c.nt - k - 1) * 4, 512, GPCC_TRSM_ROWS_LDS_BYTES, s>>>(c, g, k);
             }
             ProfScope pr(h, GPCC_PROF_SMALL_STEP, s);
             const int n = c.nt - k - 1;

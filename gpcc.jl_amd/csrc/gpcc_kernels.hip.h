@@ -25,6 +25,7 @@
     ((GPCC_TILE * GPCC_DIAG_LD + 8 * 16 * GPCC_DINV_LD + GPCC_MAXRHS * GPCC_TILE + 2 * GPCC_TILE + GPCC_MAXRHS * GPCC_MAXRHS + 3) * 8 + 16)
 static_assert(GPCC_DIAG_LDS_BYTES <= 160 * 1024, "gpcc_diag_factor's LDS image must fit the 160 KiB of a gfx950 CU");
 #define GPCC_GEMM_LDS_BYTES (2 * 2 * GPCC_CHUNK_BYTES)
+#define GPCC_TRSM_ROWS_LDS_BYTES (4 * (GPCC_CHUNK_BYTES / 4 + GPCC_CHUNK_BYTES))   /* four stages of 4 KiB + 16 KiB */
 #define GPCC_GEMM_THREADS 512
 #define GPCC_RIGHT_LOOKING_MAX 24
 
@@ -584,6 +585,120 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_trsm(GpccCtx c, GpccGroup g
             p += __shfl_xor(p, 4);
             p += __shfl_xor(p, 8);
             if (lr == 0) zp[R] = zold[r] - p;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// gpcc_panel_trsm_rows: the panel solve for a FEW evaluations (gpcc_small_step's companion).  A 128x128 tile job is ~8 us
+// of one CU's fp64 matrix pipe, and with one or two evaluations only nt-k-1 CUs would work; here a job is a QUARTER of a
+// tile (32 rows), four times as many CUs per step, and the operand stream of a job runs three chunks ahead (LDS ring of
+// four 20 KiB stages: 4 KiB of T(I,k) rows + a 16 KiB chunk of inv(L_kk)).  Wave (rh, cp): rows 16 rh .. +15 of the
+// quarter, column fragments cp and 7-cp (the triangular inverse makes fragment f need chunks <= f: every wave the same work).
+// Fused with the forward substitution z_I -= L(I,k) w_k like gpcc_panel_trsm.   grid cnt * (nt-k-1) * 4, block 512.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(512) void gpcc_panel_trsm_rows(GpccCtx c, GpccGroup g, int k)
+{
+    typedef GpccPrec<T> P;
+    constexpr int CH = GPCC_CHUNK_BYTES / sizeof(T);          // elements of a full chunk (B operand)
+    constexpr int AQ = CH / 4;                                // elements of 32 rows of a chunk (A operand)
+    constexpr int STG = AQ + CH;                              // one ring stage
+    constexpr int STAGES = 4;
+    constexpr int PIECE = 1024 / sizeof(T), EPB = 16 / sizeof(T);
+    constexpr int FPC = P::KC / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *smem = (T *)smem_raw;
+    __shared__ double sred[8][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, q = lane >> 4, sw = gpcc_sw(lr);
+    const int rh = wave & 1, cp = wave >> 1, f0 = cp, f1 = 7 - cp;
+    const int m = (int)blockIdx.x % g.cnt, rest = (int)blockIdx.x / g.cnt;
+    const int I = k + 1 + rest / 4, qr = rest % 4;
+    const int slot = g.slot0 + m;
+    if (c.info[slot] != 0) return;
+    T *Tt = (T *)c.tiles + (long)slot * c.slot_stride + gpcc_tile_off(I, k);
+    const T *gA = Tt + qr * AQ;                                        // rows 32 qr .. +31 of every chunk
+    const T *gB = (const T *)c.linv + gpcc_linv_off(c, slot, k);
+    auto dma = [&](int ch, int st) {   // three 1 KiB pieces per wave and chunk (the A pieces of waves 4-7 repeat those of 0-3)
+        T *stage = smem + st * STG;
+        const int pa = wave & 3;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gA + (long)ch * CH + pa * PIECE + lane * EPB),
+                                         (__attribute__((address_space(3))) void *)(stage + pa * PIECE), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pb = wave * 2 + i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gB + (long)ch * CH + pb * PIECE + lane * EPB),
+                                             (__attribute__((address_space(3))) void *)(stage + AQ + pb * PIECE), 16, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int pc = 0; pc < STAGES - 1 && pc < P::NCH; ++pc) dma(pc, pc);
+    typename P::acc_t acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc0[r] = acc1[r] = 0;
+    const T *pa0 = smem + (rh * 16 + lr) * P::KC + (((2 * q) ^ sw) * P::EP);
+    const T *pa1 = smem + (rh * 16 + lr) * P::KC + (((2 * q + 1) ^ sw) * P::EP);
+    const T *pb0 = smem + AQ + lr * P::KC + (((2 * q) ^ sw) * P::EP);
+    const T *pb1 = smem + AQ + lr * P::KC + (((2 * q + 1) ^ sw) * P::EP);
+    if (P::NCH >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // chunk 0 has landed (3 DMAs per chunk and wave)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int ch = 0; ch < P::NCH; ++ch) {
+        if (ch + STAGES - 1 < P::NCH) dma(ch + STAGES - 1, (ch + STAGES - 1) % STAGES);
+        const int so = (ch % STAGES) * STG;
+        typename P::v16 a[2];
+        a[0] = *(const typename P::v16 *)(pa0 + so);
+        a[1] = *(const typename P::v16 *)(pa1 + so);
+        if (f0 >= ch * FPC) {   // (wave-uniform)
+            typename P::v16 b[2];
+            b[0] = *(const typename P::v16 *)(pb0 + so + f0 * 16 * P::KC);
+            b[1] = *(const typename P::v16 *)(pb1 + so + f0 * 16 * P::KC);
+#pragma unroll
+            for (int s = 0; s < P::KSTEPS; ++s) acc0 = P::mfma(a[s / P::EP][s % P::EP], b[s / P::EP][s % P::EP], acc0);
+        }
+        if (f1 >= ch * FPC) {
+            typename P::v16 b[2];
+            b[0] = *(const typename P::v16 *)(pb0 + so + f1 * 16 * P::KC);
+            b[1] = *(const typename P::v16 *)(pb1 + so + f1 * 16 * P::KC);
+#pragma unroll
+            for (int s = 0; s < P::KSTEPS; ++s) acc1 = P::mfma(a[s / P::EP][s % P::EP], b[s / P::EP][s % P::EP], acc1);
+        }
+        if (ch + 1 < P::NCH) {
+            const int later = ((ch + STAGES - 1 < P::NCH - 1) ? ch + STAGES - 1 : P::NCH - 1) - (ch + 1);   // chunks issued beyond ch+1
+            if (later <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    const int row0 = qr * 32 + rh * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        Tt[gpcc_elem_off<T>(row0 + P::crow(q, r), f0 * 16 + lr)] = acc0[r];
+        Tt[gpcc_elem_off<T>(row0 + P::crow(q, r), f1 * 16 + lr)] = acc1[r];
+    }
+    // forward substitution: z_I[row] -= sum_c L(I,k)[row][c] w_k[c]; a wave holds 32 of the 128 columns of its 16 rows
+    for (int j = 0; j < c.nrhs; ++j) {
+        double *zp = c.z + ((long)slot * c.nrhs + j) * c.Np + I * GPCC_TILE;
+        const double *wp = c.w + ((long)slot * c.nrhs + j) * c.Np + k * GPCC_TILE;
+        const double w0 = wp[f0 * 16 + lr], w1 = wp[f1 * 16 + lr];
+        __syncthreads();   // (sred of the previous right-hand side has been consumed)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double pr = (double)acc0[r] * w0 + (double)acc1[r] * w1;
+            pr += __shfl_xor(pr, 1);
+            pr += __shfl_xor(pr, 2);
+            pr += __shfl_xor(pr, 4);
+            pr += __shfl_xor(pr, 8);
+            if (lr == 0) sred[wave][P::crow(q, r)] = pr;
+        }
+        __syncthreads();
+        if (tid < 32) {   // row tid of the quarter: half rh2, the four column pairs in a fixed order
+            const int rh2 = tid >> 4, rr = tid & 15;
+            const double sum = ((sred[rh2][rr] + sred[2 + rh2][rr]) + sred[4 + rh2][rr]) + sred[6 + rh2][rr];
+            zp[qr * 32 + tid] -= sum;
         }
     }
 }
