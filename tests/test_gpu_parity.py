@@ -869,6 +869,25 @@ def test_handle_lifetimes_leave_no_device_memory_behind(gp):
     assert abs(free - free0) < 64 * 2**20, (free0, free)
 
 
+def test_constant_band_zero_prior_variance(gp, oracle):
+    """A band of constant fluxes has Sigma_b = 100 var(y_l) = 0: K = delayedCovariance + Sobs (+ B of the other bands) is
+    still positive definite and the reference returns a finite log-likelihood.  The fp32 path's capacitance system
+    (Woodbury) must drop that column instead of dividing by zero; postb has no meaning there (inv(Sigma_b))."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([150, 140, 90], seed=9)
+    y[1] = np.full_like(y[1], 4.25)
+    delays, alpha, rho = [[0.0, 1.0, 3.0], [0.0, 4.0, 2.0]], [[1.1, 0.7, 1.9], [0.8, 1.0, 1.2]], [2.5, 4.0]
+    ref, rinfo = oracle.loglik_batch("matern32", t, y, s, delays, alpha, rho, True)
+    assert (rinfo == 0).all() and np.all(np.isfinite(ref))
+    for prec, tol in (("fp64", LL_RTOL), ("fp32", FP32_RTOL)):
+        with gp.Objective(t, y, s, gp.matern32, precision=prec) as obj:
+            ll, info = obj.loglik_batch(delays, alpha, rho)
+            assert (info == 0).all() and _rel(ll, ref) <= tol, (prec, ll, ref)
+            assert obj.constants()[1][1] == 0.0
+            with pytest.raises(gp.GpccError):
+                obj.posterior_offsets(delays[0], alpha[0], rho[0])
+
+
 # ---- multi-device handles behind the C ABI (gpcc_create_multi; SURVEY 8(b)/(e)) ---------------------------------
 def test_multi_device_handle_matches_single_device(gp, oracle):
     """device_ids = [0]: bitwise equal to the single-device handle.  device_ids = [0, 0] (the one-GPU rehearsal of the
