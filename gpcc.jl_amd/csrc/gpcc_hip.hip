@@ -36,7 +36,7 @@ struct gpcc_handle_s {
     std::vector<int> band_host;
     // options
     int streams = 1, slots_per_stream = 256, right_looking_max = GPCC_RIGHT_LOOKING_MAX;
-    int fused_small_max = 4;   // groups of at most this many evaluations run gpcc_small_step (update + next diagonal step in one launch)
+    int fused_small_max = 12;  // groups of at most this many evaluations run gpcc_small_step (update + next diagonal step in one launch)
     int shared_prefix = 1;   // 0 off, 1 auto (host-pointer API detects it), 2 the caller asserts it
     int share_tiles = 0;     // tile rows wholly inside band 1
     bool share_now = false;  // decision for the batch being enqueued
@@ -363,7 +363,8 @@ extern "C" int gpcc_get_conditioning(gpcc_handle_t h, int M, double *out)
     return 0;
 }
 
-// the diagonal kernel needs 149 KiB of dynamic LDS, the MFMA kernels 64 KiB (per device, idempotent)
+// the diagonal kernel (and gpcc_small_step, which contains it) needs GPCC_DIAG_LDS_BYTES = 158.7 KiB of dynamic LDS (static_assert
+// against the 160 KiB of a CU in gpcc_kernels.hip.h), the MFMA kernels 64 KiB, the quarter-tile solve 80 KiB (per device, idempotent)
 static int set_kernel_attributes(gpcc_handle_t h)
 {
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_diag_factor<double>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_DIAG_LDS_BYTES));

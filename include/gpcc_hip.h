@@ -81,7 +81,7 @@ int gpcc_multi_gathered(gpcc_handle_t handle, int which, long *blk_out, double *
 /* Tunables: "streams" (groups in flight on separate HIP streams, default 1), "slots_per_stream"
  * (evaluations resident per group, default 256 = one diagonal-block workgroup per CU, capped so
  * the workspace stays under 64 GiB), "right_looking_max" (groups of at most this many evaluations use
- * the right-looking update, default 24), "fused_small_max" (groups of at most this many evaluations, default 4, run the
+ * the right-looking update, default 24), "fused_small_max" (groups of at most this many evaluations, default 12, run the
  * trailing update of a step and the next diagonal step in ONE launch: the latency path of a single objective(alpha, rho)),
  * "shared_prefix" (0 off; 1 = default: gpcc_loglik_batch detects a
  * batch whose evaluations all have the same band-1 amplitude, delay and rho -- a fixed-hyper-parameter delay
