@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--shared-extra", action="store_true",
                     help="also time the sweep with the shared-prefix mode asserted (reported separately, never as `value`)")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="CPU baseline: evaluations per worker process (0: 6)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="CPU baseline: evaluations per worker process (0: 24)")
     args = ap.parse_args()
 
     import torch
@@ -236,7 +236,7 @@ def main():
         nsample = 8
         idx = np.linspace(0, G - 1, nsample).astype(int)
         cmd = [sys.executable, "-m", "oracle.lapack_baseline", "--n-per-band", str(Nb), "--bands", str(L), "--kernel", args.kernel,
-               "--seed", str(args.seed), "--delays", json.dumps(delays[idx].tolist()), "--evals-per-worker", str(args.cpu_sample or 6)]
+               "--seed", str(args.seed), "--delays", json.dumps(delays[idx].tolist()), "--evals-per-worker", str(args.cpu_sample or 24)]
         c0 = time.perf_counter()
         run = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
         cpu_s = time.perf_counter() - c0
