@@ -38,6 +38,8 @@ struct gpcc_handle_s {
     int streams = 1, slots_per_stream = 256, right_looking_max = GPCC_RIGHT_LOOKING_MAX;
     int fused_small_max = 12;  // groups of at most this many evaluations run gpcc_small_step (update + next diagonal step in one launch)
     int shared_prefix = 1;   // 0 off, 1 auto (host-pointer API detects it), 2 the caller asserts it
+    int update_t = 0;        // EXPERIMENT: transposed-accumulator update kernel
+    int fused_solve = 1;     // option "fused_solve": left-looking groups run gpcc_syrk_diag + gpcc_update_solve (2 launches per step)
     int share_tiles = 0;     // tile rows wholly inside band 1
     bool share_now = false;  // decision for the batch being enqueued
     // workspace
@@ -308,6 +310,10 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->right_looking_max = (int)v;
     } else if (!strcmp(key, "fused_small_max")) {
         h->fused_small_max = (int)v;
+    } else if (!strcmp(key, "update_t")) {
+        h->update_t = (int)v;
+    } else if (!strcmp(key, "fused_solve")) {
+        h->fused_solve = v != 0;
     } else if (!strcmp(key, "fp32_guard")) {
         h->fp32_guard = v != 0;
     } else if (!strcmp(key, "fp32_refine")) {
@@ -337,6 +343,7 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "Np")) return h->Np;
     if (!strcmp(key, "bytes_per_slot")) return (long)(((long)h->nt * (h->nt + 1) / 2 + (h->precision ? h->nt : 1)) * GPCC_TILE_ELEMS) * (h->precision ? 4 : 8) + 16L * h->Np * h->nrhs;
     if (!strcmp(key, "precision")) return h->precision;
+    if (!strcmp(key, "fused_solve")) return h->fused_solve;
     if (!strcmp(key, "fp32_guard")) return h->fp32_guard;
     if (!strcmp(key, "fp32_refine")) return h->fp32_refine;
     if (!strcmp(key, "fp32_guard_count")) return h->fb_count;
@@ -370,8 +377,14 @@ static int set_kernel_attributes(gpcc_handle_t h)
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_diag_factor<double>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_DIAG_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_diag_factor<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_DIAG_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_small_step<double>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_DIAG_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_syrk_diag<double>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_DIAG_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_syrk_diag<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_DIAG_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_small_step<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_DIAG_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<double, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_update_solve<double, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_update_solve<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_update_solve<double, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_update_solve<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<double, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
@@ -517,11 +530,27 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
         }
         return;
     }
+    if (!right && !p && c.nt_fact == c.nt && h->fused_solve && !c.store_l) {
+        // left-looking, the panel solve inside the update (gpcc_update_solve): per step the diagonal tile first
+        // (gpcc_syrk_diag: lower-triangle update + diagonal step in one workgroup per evaluation), then the rest of column k
+        for (int k = 0; k < c.nt; ++k) {
+            {
+                ProfScope pr(h, GPCC_PROF_DIAG, s);
+                gpcc_syrk_diag<T><<<g.cnt, 512, GPCC_DIAG_LDS_BYTES, s>>>(c, g, k);
+            }
+            if (k < c.nt - 1) {
+                ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
+                gpcc_update_solve<T, true><<<cnt8 * (c.nt - k - 1), GPCC_GEMM_THREADS, GPCC_UPSOLVE_LDS_BYTES, s>>>(c, g, k);
+            }
+        }
+        return;
+    }
     for (int k = 0; k < c.nt_fact; ++k) {
         if (k > 0 && !right) {
             ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
             const int grid = (k < p) ? cnt8 * (c.nt - p) + (p - k) : cnt8 * (c.nt - k);
-            gpcc_panel_update<T, false><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, k);
+            if (h->update_t && !p && c.nt_fact == c.nt) gpcc_update_solve<T, false><<<grid, GPCC_GEMM_THREADS, GPCC_UPSOLVE_LDS_BYTES, s>>>(c, g, k);
+            else gpcc_panel_update<T, false><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, k);
         }
         {
             ProfScope pr(h, GPCC_PROF_DIAG, s);

@@ -482,6 +482,188 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
 }
 
 // ------------------------------------------------------------------------------------------
+// gpcc_update_solve (step k, tile I > k; left-looking groups): the panel update AND the panel solve of tile (I,k) in one
+// job --  T'(I,k) = T(I,k) - sum_{j<k} L(I,j) L(k,j)^T ;  L(I,k) = T'(I,k) inv(L_kk)^T ;  z_I -= L(I,k) w_k  -- so the
+// updated tile never makes the round trip "written by the update, read and rewritten by the solve" (256 KiB per tile at
+// ~4.3 TB/s: gpcc_panel_trsm is HBM-bound).  inv(L_kk) must exist when the job runs: the diagonal tile of column k is
+// updated and factored first (gpcc_syrk_diag), then this kernel takes the rest of the column.
+// The trick that keeps it inside the 128-register budget: the main loop accumulates the TRANSPOSED tile -- wave w owns
+// T'^T[all 128 columns c][rows r = 16 w .. 16 w + 15] as eight 16x16 blocks (MFMA A operand = tile row k, B operand = tile
+// row I) -- because a 16x16 accumulator block, as it sits in registers, IS a valid MFMA B operand whose k index is its ROW
+// index (C/D layout: row = crow(q, reg), col = lane & 15).  So  L^T = X T'^T  (X = inv(L_kk), lower triangular) is
+// out[i] = sum_{cf <= i} X[i][cf] acc[cf]  with the X blocks as A operands read from LDS and the accumulators as B operands
+// straight from registers; going down from i = 7, block acc[i] is dead once out[i] is formed, so out[i] replaces it: one
+// spare accumulator.  The lower blocks of X (72 KiB in fp64) are DMA'd into LDS after the K-loop (80 KiB of LDS per
+// workgroup: still two workgroups per CU).  The result leaves through LDS in the tile's own byte layout, so the global
+// stores are linear 16-byte copies.
+// SOLVE = false: update only, tiles I >= k (drop-in for gpcc_panel_update<T, false>; used to A/B the transposed main loop).
+// grid 8 * ceil(cnt / 8) * (nt - k - (SOLVE ? 1 : 0)), block 512.
+// ------------------------------------------------------------------------------------------
+#define GPCC_UPSOLVE_LDS_BYTES (80 * 1024)
+template <typename T, bool SOLVE>
+__global__ __launch_bounds__(512, 4) void gpcc_update_solve(GpccCtx c, GpccGroup g, int k)
+{
+    typedef GpccPrec<T> P;
+    constexpr int CH = GPCC_CHUNK_BYTES / sizeof(T);
+    constexpr int PIECE = 1024 / sizeof(T), EPB = 16 / sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *smem = (T *)smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, q = lane >> 4;
+    const int sw = gpcc_sw(lr);
+    const int per = c.nt - k - (SOLVE ? 1 : 0);
+    const int x = blockIdx.x & 7, qq = blockIdx.x >> 3;
+    const int m = g.spread ? (int)blockIdx.x % g.cnt : (qq / per) * 8 + x;
+    if (m >= g.cnt) return;
+    const int I = k + (SOLVE ? 1 : 0) + (g.spread ? (int)blockIdx.x / g.cnt : qq % per);
+    const int slot = g.slot0 + m;
+    if (c.info[slot] != 0) return;
+    T *tiles = (T *)c.tiles + (long)slot * c.slot_stride;
+    const T *gI = tiles + gpcc_tile_off(I, 0);   // tile row I: MFMA B operand (this wave's 16 rows)
+    const T *gK = tiles + gpcc_tile_off(k, 0);   // tile row k: MFMA A operand (all 128 rows)
+    T *Tt = tiles + gpcc_tile_off(I, k);
+    const int nch = P::NCH * k;
+    if (nch > 0) gpcc_dma_chunk<T>(gI, gK, smem, wave, lane);
+
+    typename P::acc_t acc[8];   // acc[cf][r'] = -T'^T[c = 16 cf + crow(q, r')][r = 16 wave + lr]
+#pragma unroll
+    for (int cf = 0; cf < 8; ++cf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[cf][r] = -Tt[gpcc_elem_off<T>(wave * 16 + lr, cf * 16 + P::crow(q, r))];
+
+    const T *pb0 = smem + (wave * 16 + lr) * P::KC + (((2 * q) ^ sw) * P::EP);        // stage: [row I chunk | row k chunk]
+    const T *pb1 = smem + (wave * 16 + lr) * P::KC + (((2 * q + 1) ^ sw) * P::EP);
+    const T *pa0 = smem + CH + lr * P::KC + (((2 * q) ^ sw) * P::EP);
+    const T *pa1 = smem + CH + lr * P::KC + (((2 * q + 1) ^ sw) * P::EP);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ch2 = 0; ch2 < nch; ch2 += 2) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {  // stage st holds chunk ch2+st (nch is even)
+            const int ch = ch2 + st;
+            if (ch + 1 < nch)
+                gpcc_dma_chunk<T>(gI + (long)(ch + 1) * CH, gK + (long)(ch + 1) * CH, smem + (st ^ 1) * 2 * CH, wave, lane);
+            const int so = st * 2 * CH;
+            typename P::v16 b[2];
+            b[0] = *(const typename P::v16 *)(pb0 + so);
+            b[1] = *(const typename P::v16 *)(pb1 + so);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {  // row-k fragments four at a time (register budget: 128)
+                typename P::v16 a[4][2];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    a[f][0] = *(const typename P::v16 *)(pa0 + so + (4 * h + f) * 16 * P::KC);
+                    a[f][1] = *(const typename P::v16 *)(pa1 + so + (4 * h + f) * 16 * P::KC);
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < P::KSTEPS; ++s2)
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+                        acc[4 * h + f] = P::mfma(a[f][s2 / P::EP][s2 % P::EP], b[s2 / P::EP][s2 % P::EP], acc[4 * h + f]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    if (SOLVE) {
+        // ---- lower blocks of X = inv(L_kk) -> LDS, packed chunk by chunk: chunk ch2 of the tile holds columns KC ch2 .. of all
+        // 128 rows; rows above the chunk's first column block are zero and skipped.  Block (i, cf) is then read at
+        // xbase(cf) + rows 16 i ..: element (R, col) at xoff[chunk] + (R - R0[chunk]) KC + swizzled slot.
+        constexpr int FPC = P::KC / 16;                       // 16-column blocks per chunk (fp64: 1, fp32: 2)
+        const T *gX = (const T *)c.linv + gpcc_linv_off(c, slot, k);
+        int xoff[P::NCH];                                     // (compile-time after unrolling)
+        {
+            int o = 0;
+#pragma unroll
+            for (int ch = 0; ch < P::NCH; ++ch) {
+                xoff[ch] = o;
+                o += (GPCC_TILE - 16 * FPC * ch) * P::KC;     // rows 16 FPC ch .. 127
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < P::NCH; ++ch) {
+            const int r0x = 16 * FPC * ch, npiece = (GPCC_TILE - r0x) * P::KC / PIECE;   // 1 KiB pieces of this chunk's lower rows
+            for (int pc = wave; pc < npiece; pc += 8)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gX + (long)ch * CH + r0x * P::KC + pc * PIECE + lane * EPB),
+                                                 (__attribute__((address_space(3))) void *)(smem + xoff[ch] + pc * PIECE), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        auto xload = [&](int i, int cf, T (&xa)[4]) {   // A operand of block (i, cf): X[16 i + lr][16 cf + crow(q, s2)], s2 = 0..3
+            const int ch = cf / FPC, r0x = 16 * FPC * ch;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const int col = (cf % FPC) * 16 + P::crow(q, s2);      // column inside the chunk
+                xa[s2] = smem[xoff[ch] + (16 * i + lr - r0x) * P::KC + (((col / P::EP) ^ sw) * P::EP) + (col % P::EP)];
+            }
+        };
+        T xcur[4], xnxt[4];
+        xload(7, 0, xcur);
+#pragma unroll
+        for (int i = 7; i >= 0; --i) {
+            typename P::acc_t t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = 0;
+#pragma unroll
+            for (int cf = 0; cf <= i; ++cf) {
+                // the next block's four values are requested before this block's MFMAs (the accumulator block's row index is
+                // its k index: k-step s2 pairs X[..][16 cf + crow(q, s2)] with register s2 of acc[cf])
+                if (cf < i) xload(i, cf + 1, xnxt);
+                else if (i > 0) xload(i - 1, 0, xnxt);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) t = P::mfma(xcur[s2], acc[cf][s2], t);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) xcur[s2] = xnxt[s2];
+                __builtin_amdgcn_sched_barrier(0);   // keep the 144 LDS reads of this epilogue from being hoisted into registers
+            }
+            acc[i] = t;   // = -L^T block i (acc was -T'^T); blocks > i are final, blocks < i still hold -T'^T
+        }
+        __syncthreads();   // every wave is done with X before the output staging overwrites it
+    }
+    // ---- out through LDS in the tile's own byte layout (rows 64 h .. 64 h + 63 of every chunk = 64 KiB in fp64), then linear
+    // 16-byte copies to global; L = -acc (resp. T' = -acc)
+    constexpr int HALVES = (int)(sizeof(T) * GPCC_TILE_ELEMS / 65536);   // fp64: 2, fp32: 1
+    constexpr int HROWS = GPCC_TILE / HALVES;
+#pragma unroll
+    for (int hv = 0; hv < HALVES; ++hv) {
+        if (wave * 16 / HROWS == hv) {
+            const int rl = wave * 16 + lr - hv * HROWS;   // row inside the half
+#pragma unroll
+            for (int cf = 0; cf < 8; ++cf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = cf * 16 + P::crow(q, r), ch = col / P::KC, cc = col % P::KC;
+                    smem[ch * (HROWS * P::KC) + rl * P::KC + (((cc / P::EP) ^ sw) * P::EP) + (cc % P::EP)] = -acc[cf][r];
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ch = 0; ch < P::NCH; ++ch) {
+            constexpr int PER = HROWS * P::KC / P::EP;   // 16-byte pieces of this half's rows in one chunk
+            for (int pc = tid; pc < PER; pc += 512)
+                *(typename P::v16 *)(Tt + (long)ch * CH + hv * HROWS * P::KC + pc * P::EP) =
+                    *(const typename P::v16 *)(smem + ch * (HROWS * P::KC) + pc * P::EP);
+        }
+        if (hv + 1 < HALVES) __syncthreads();
+    }
+    if (SOLVE) {
+        // forward substitution of logpdf's whitening: z_I[r] -= sum_c L(I,k)[r][c] w_k[c]; a wave owns its 16 rows completely
+        for (int j = 0; j < c.nrhs; ++j) {
+            double *zp = c.z + ((long)slot * c.nrhs + j) * c.Np + I * GPCC_TILE;
+            const double *wp = c.w + ((long)slot * c.nrhs + j) * c.Np + k * GPCC_TILE;
+            double pr = 0.0;
+#pragma unroll
+            for (int cf = 0; cf < 8; ++cf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pr = fma(-(double)acc[cf][r], wp[cf * 16 + P::crow(q, r)], pr);
+            pr += __shfl_xor(pr, 16);
+            pr += __shfl_xor(pr, 32);
+            if (q == 0) zp[wave * 16 + lr] -= pr;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // gpcc_panel_trsm (step k, tile I > k):  L(I,k) = T(I,k) inv(L_kk)^T  (dtrsm as an MFMA product
 // with the explicit 128x128 inverse from gpcc_diag_factor; chunks of inv(L_kk) above the diagonal
 // are zero and skipped), fused with the forward substitution of logpdf's whitening for every
@@ -1322,6 +1504,102 @@ __global__ __launch_bounds__(512) void gpcc_small_step(GpccCtx c, GpccGroup g, i
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 Tt[gpcc_elem_off<T>(wr * 32 + fm * 16 + P::crow(q, r), wc * 64 + fn * 16 + lr)] = -acc[fm][fn][r];
+}
+
+// ------------------------------------------------------------------------------------------
+// gpcc_syrk_diag (step k; companion of gpcc_update_solve): one workgroup per evaluation -- the lower triangle of the
+// diagonal tile, T'(k,k) = T(k,k) - sum_{j<k} L(k,j) L(k,j)^T (36 of 64 blocks, dealt to the waves like
+// gpcc_small_diag_tile; ONE operand stream: both MFMA operands are fragments of tile row k), through a 4-stage LDS ring
+// (one workgroup per CU: nothing else hides the load latency), then straight on into the diagonal step with the tile
+// handed over in LDS.  grid cnt, block 512, LDS = the diagonal image.
+// ------------------------------------------------------------------------------------------
+template <typename T, int RA, int CA, int NA, int RB, int CB, int NB>
+__device__ __forceinline__ void gpcc_syrk_lower_wave(const T *gRow, int nch, T *smem, const T *Tt, double *smem_d, int wave, int lane)
+{
+    typedef GpccPrec<T> P;
+    constexpr int CH = GPCC_CHUNK_BYTES / sizeof(T), PIECE = 1024 / sizeof(T), EPB = 16 / sizeof(T), STAGES = 4;
+    const int lr = lane & 15, q = lane >> 4, sw = gpcc_sw(lr);
+    auto dma = [&](int ch) {   // two 1 KiB pieces per wave and chunk
+        T *stage = smem + (ch % STAGES) * CH;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pc = wave * 2 + i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gRow + (long)ch * CH + pc * PIECE + lane * EPB),
+                                             (__attribute__((address_space(3))) void *)(stage + pc * PIECE), 16, 0, 0);
+        }
+    };
+    typename P::acc_t acc[NA + NB];
+#pragma unroll
+    for (int i = 0; i < NA + NB; ++i) {
+        const int R = (i < NA) ? RA : RB, C = (i < NA) ? CA + i : CB + (i - NA);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] = -Tt[gpcc_elem_off<T>(16 * R + P::crow(q, r), 16 * C + lr)];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the accumulator loads: the DMA counting below starts clean)
+    for (int pc = 0; pc < STAGES - 1 && pc < nch; ++pc) dma(pc);
+    const T *p0 = smem + lr * P::KC + (((2 * q) ^ sw) * P::EP);
+    const T *p1 = smem + lr * P::KC + (((2 * q + 1) ^ sw) * P::EP);
+    for (int ch = 0; ch < nch; ++ch) {
+        // chunk ch must have landed; chunks ch+1, ch+2 (issued earlier) may still fly: 2 DMAs per chunk and wave.  ONE barrier
+        // per chunk: behind it every wave has its pieces of chunk ch in LDS and has finished chunk ch-1, whose stage
+        // ((ch-1) % 4 = (ch+3) % 4) is therefore free for the DMA of chunk ch+3 issued right after.
+        const int later = ((ch + STAGES - 2 < nch - 1) ? ch + STAGES - 2 : nch - 1) - ch;
+        if (later >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ch + STAGES - 1 < nch) dma(ch + STAGES - 1);
+        const int so = (ch % STAGES) * CH;
+        typename P::v16 aA[2], aB[2];
+        aA[0] = *(const typename P::v16 *)(p0 + so + RA * 16 * P::KC);
+        aA[1] = *(const typename P::v16 *)(p1 + so + RA * 16 * P::KC);
+        if (NB > 0) {
+            aB[0] = *(const typename P::v16 *)(p0 + so + RB * 16 * P::KC);
+            aB[1] = *(const typename P::v16 *)(p1 + so + RB * 16 * P::KC);
+        }
+#pragma unroll
+        for (int i = 0; i < NA + NB; ++i) {
+            const int C = (i < NA) ? CA + i : CB + (i - NA);
+            typename P::v16 b[2];
+            b[0] = *(const typename P::v16 *)(p0 + so + C * 16 * P::KC);
+            b[1] = *(const typename P::v16 *)(p1 + so + C * 16 * P::KC);
+#pragma unroll
+            for (int s = 0; s < P::KSTEPS; ++s)
+                acc[i] = P::mfma((i < NA) ? aA[s / P::EP][s % P::EP] : aB[s / P::EP][s % P::EP], b[s / P::EP][s % P::EP], acc[i]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NA + NB; ++i) {
+        const int R = (i < NA) ? RA : RB, C = (i < NA) ? CA + i : CB + (i - NA);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) smem_d[(16 * R + P::crow(q, r)) * GPCC_DIAG_LD + 16 * C + lr] = (double)(T)(-acc[i][r]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void gpcc_syrk_diag(GpccCtx c, GpccGroup g, int k)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem_d[];
+    T *smem = (T *)smem_d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = blockIdx.x, slot = g.slot0 + m;
+    if (c.info[slot] == 0) {
+        const T *tiles = (const T *)c.tiles + (long)slot * c.slot_stride;
+        const T *gRow = tiles + gpcc_tile_off(k, 0), *Tt = tiles + gpcc_tile_off(k, k);
+        const int nch = GpccPrec<T>::NCH * k;
+        switch (__builtin_amdgcn_readfirstlane(wave)) {
+        case 0: gpcc_syrk_lower_wave<T, 7, 0, 5, 0, 0, 0>(gRow, nch, smem, Tt, smem_d, wave, lane); break;
+        case 1: gpcc_syrk_lower_wave<T, 6, 0, 5, 0, 0, 0>(gRow, nch, smem, Tt, smem_d, wave, lane); break;
+        case 2: gpcc_syrk_lower_wave<T, 5, 0, 5, 0, 0, 0>(gRow, nch, smem, Tt, smem_d, wave, lane); break;
+        case 3: gpcc_syrk_lower_wave<T, 4, 0, 5, 0, 0, 0>(gRow, nch, smem, Tt, smem_d, wave, lane); break;
+        case 4: gpcc_syrk_lower_wave<T, 7, 5, 3, 0, 0, 1>(gRow, nch, smem, Tt, smem_d, wave, lane); break;
+        case 5: gpcc_syrk_lower_wave<T, 6, 5, 2, 1, 0, 2>(gRow, nch, smem, Tt, smem_d, wave, lane); break;
+        case 6: gpcc_syrk_lower_wave<T, 5, 5, 1, 2, 0, 3>(gRow, nch, smem, Tt, smem_d, wave, lane); break;
+        default: gpcc_syrk_lower_wave<T, 3, 0, 4, 0, 0, 0>(gRow, nch, smem, Tt, smem_d, wave, lane); break;
+        }
+    }
+    gpcc_diag_body<T, true>(c, g, k, m, smem_d);   // (a failed evaluation is reported there)
 }
 
 // ------------------------------------------------------------------------------------------

@@ -660,10 +660,13 @@ def test_shared_prefix_is_bitwise_identical(gp, Nl, prec):
     with gp.Objective(t, y, s, gp.matern32, precision=prec, slots_per_stream=40) as obj:
         assert obj.get_option("share_tiles") == Nl[0] // 128
         obj.set_option("shared_prefix", 0)
+        dflt, dinfo = obj.loglik_batch(delays, alphas, rhos)     # default plain path: panel solve fused into the update
+        obj.set_option("fused_solve", 0)           # the three-kernel path, whose kernels the shared-prefix mode runs
         ref, rinfo = obj.loglik_batch(delays, alphas, rhos)
         obj.set_option("shared_prefix", 1)         # auto: the host-pointer API sees identical band-1 parameters
         ll, info = obj.loglik_batch(delays, alphas, rhos)
         assert (rinfo == 0).all() and np.array_equal(info, rinfo) and np.array_equal(ll, ref)
+        assert (dinfo == 0).all() and _rel(dflt, ref) <= (1e-11 if prec == "fp64" else 1e-5)   # same arithmetic, other summation order
         # not shareable (band-1 delay differs): auto mode must fall back to the plain path
         d2 = delays.copy()
         d2[3, 0] = 0.25
@@ -903,9 +906,11 @@ def test_multi_device_handle_matches_single_device(gp, oracle):
     alphas[5, 1] = -1.0                      # an invalid point inside the first block
     rhos[30] = 0.0                           # and one inside the second
     # left- and right-looking updates round differently and the choice follows the group size, which sharding
-    # changes: pin the left-looking form on both sides for the bitwise comparison
+    # changes: pin the left-looking form on both sides for the bitwise comparison; likewise the shared-prefix mode
+    # (a block of a sharded batch may be shareable where the whole batch is not; its kernels sum in another order)
     with gp.Objective(t, y, s, gp.matern32) as single:
         single.set_option("right_looking_max", 0)
+        single.set_option("shared_prefix", 0)
         ref, rinfo = single.loglik_batch(delays, alphas, rhos)
         fit_ref = single.grid_loglik(delays[:6], 8, seed=3)
     assert rinfo[5] == -1 and rinfo[30] == -2 and (np.delete(rinfo, [5, 30]) == 0).all()
@@ -913,6 +918,7 @@ def test_multi_device_handle_matches_single_device(gp, oracle):
         with gp.Objective(t, y, s, gp.matern32, devices=devs) as multi:
             assert multi.get_option("n_devices") == len(devs) and multi.get_option("gather_mode") == mode
             multi.set_option("right_looking_max", 0)       # applies to every device
+            multi.set_option("shared_prefix", 0)
             ll, info = multi.loglik_batch(delays, alphas, rhos)
             assert np.array_equal(ll, ref, equal_nan=True) and np.array_equal(info, rinfo), devs
             blk = -(-M // len(devs))
