@@ -872,6 +872,40 @@ def test_handle_lifetimes_leave_no_device_memory_behind(gp):
     assert abs(free - free0) < 64 * 2**20, (free0, free)
 
 
+@pytest.mark.parametrize("Nl,prec,tol", [([300, 280], "fp64", 1e-11), ([129], "fp64", 1e-11), ([520, 500, 490], "fp64", 1e-11),
+                                         ([384, 300], "fp32", 1e-5)])
+def test_fused_solve_path_agrees_with_three_kernel_path(gp, oracle, Nl, prec, tol):
+    """The default left-looking path (gpcc_syrk_diag + gpcc_update_solve: panel solve inside the update) against
+    the round-1 kernels (update / diagonal / solve as three launches, `fused_solve` = 0) and against the oracle: same
+    arithmetic in another summation order.  Group sizes above and below 8 (the job map differs), a ragged last tile, an
+    invalid and a non-positive-definite evaluation in the batch."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves(Nl, seed=13)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    L = len(Nl)
+    for M in (3, 41):
+        rng = np.random.default_rng(M)
+        delays = np.concatenate([np.zeros((M, 1)), rng.random((M, L - 1)) * 12], 1)
+        alphas = np.tile(alpha, (M, 1)) * (0.5 + rng.random((M, L)))
+        rhos = rho * (0.5 + rng.random(M))
+        alphas[1, 0] = 0.0                       # argument error: info -1
+        with gp.Objective(t, y, s, gp.matern52, precision=prec, slots_per_stream=16) as obj:
+            obj.set_option("right_looking_max", 0)    # left-looking also for the group of 3
+            obj.set_option("shared_prefix", 0)
+            assert obj.get_option("fused_solve") == 1
+            a, ia = obj.loglik_batch(delays, alphas, rhos)
+            a2, ia2 = obj.loglik_batch(delays, alphas, rhos)
+            obj.set_option("fused_solve", 0)
+            b, ib = obj.loglik_batch(delays, alphas, rhos)
+        assert np.array_equal(a, a2, equal_nan=True) and np.array_equal(ia, ia2)      # repeatable
+        assert np.array_equal(ia, ib) and ia[1] == -1 and (np.delete(ia, 1) == 0).all()
+        ok = ia == 0
+        assert _rel(a[ok], b[ok]) <= tol
+        ref, rinfo = oracle.loglik_batch("matern52", t, y, s, delays, alphas, rhos, True, nthreads=8)
+        assert np.array_equal(rinfo == 0, ok)
+        assert _rel(a[ok], ref[ok]) <= (LL_RTOL if prec == "fp64" else FP32_RTOL)
+
+
 def test_constant_band_zero_prior_variance(gp, oracle):
     """A band of constant fluxes has Sigma_b = 100 var(y_l) = 0: K = delayedCovariance + Sobs (+ B of the other bands) is
     still positive definite and the reference returns a finite log-likelihood.  The fp32 path's capacitance system
