@@ -1350,169 +1350,11 @@ __global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c,
     gpcc_diag_body<T, false>(c, g, k, blockIdx.x, smem);
 }
 
-// The tile (k+1,k+1) of gpcc_small_step sits on the critical path of a single evaluation (update -> diagonal step ->
-// panel solve -> update ...) and the diagonal step only reads its lower triangle: 36 of the 64 16x16 blocks, dealt
-// 5/5/5/5/4/4/4/4 to the eight waves (waves w and w+4 share a SIMD: one 5-block and one 4-block wave each) -- 56 % of the
-// MFMA time of the full tile.  Wave-specialised: NA blocks (RA, CA..CA+NA-1) and NB blocks (RB, CB..CB+NB-1).
-template <typename T, int RA, int CA, int NA, int RB, int CB, int NB>
-__device__ __forceinline__ void gpcc_small_diag_tile(const T *gA, const T *gB, T *smem, const T *Tt, double *smem_d, int wave, int lane)
-{
-    typedef GpccPrec<T> P;
-    constexpr int CH = GPCC_CHUNK_BYTES / sizeof(T);
-    const int lr = lane & 15, q = lane >> 4, sw = gpcc_sw(lr);
-    typename P::acc_t acc[NA + NB];
-#pragma unroll
-    for (int i = 0; i < NA + NB; ++i) {
-        const int R = (i < NA) ? RA : RB, C = (i < NA) ? CA + i : CB + (i - NA);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][r] = -Tt[gpcc_elem_off<T>(16 * R + P::crow(q, r), 16 * C + lr)];
-    }
-    const T *p0 = smem + lr * P::KC + (((2 * q) ^ sw) * P::EP);       // row lr of a 16-row fragment, slots 2q / 2q+1
-    const T *p1 = smem + lr * P::KC + (((2 * q + 1) ^ sw) * P::EP);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll 2
-    for (int ch = 0; ch < P::NCH; ++ch) {
-        const int st = ch & 1;
-        if (ch + 1 < P::NCH)
-            gpcc_dma_chunk<T>(gA + (long)(ch + 1) * CH, gB + (long)(ch + 1) * CH, smem + (st ^ 1) * 2 * CH, wave, lane);
-        const int so = st * 2 * CH;
-        typename P::v16 aA[2], aB[2];
-        aA[0] = *(const typename P::v16 *)(p0 + so + RA * 16 * P::KC);
-        aA[1] = *(const typename P::v16 *)(p1 + so + RA * 16 * P::KC);
-        if (NB > 0) {
-            aB[0] = *(const typename P::v16 *)(p0 + so + RB * 16 * P::KC);
-            aB[1] = *(const typename P::v16 *)(p1 + so + RB * 16 * P::KC);
-        }
-#pragma unroll
-        for (int i = 0; i < NA + NB; ++i) {
-            const int C = (i < NA) ? CA + i : CB + (i - NA);
-            typename P::v16 b[2];
-            b[0] = *(const typename P::v16 *)(p0 + so + CH + C * 16 * P::KC);
-            b[1] = *(const typename P::v16 *)(p1 + so + CH + C * 16 * P::KC);
-#pragma unroll
-            for (int s = 0; s < P::KSTEPS; ++s)
-                acc[i] = P::mfma((i < NA) ? aA[s / P::EP][s % P::EP] : aB[s / P::EP][s % P::EP], b[s / P::EP][s % P::EP], acc[i]);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    // hand the updated blocks (rounded to T, as the unfused path stores them) over to the diagonal step's LDS image
-#pragma unroll
-    for (int i = 0; i < NA + NB; ++i) {
-        const int R = (i < NA) ? RA : RB, C = (i < NA) ? CA + i : CB + (i - NA);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) smem_d[(16 * R + P::crow(q, r)) * GPCC_DIAG_LD + 16 * C + lr] = (double)(T)(-acc[i][r]);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// gpcc_small_step (step k of a group of a FEW evaluations, e.g. the single objective(alpha, rho) of Nelder-Mead): the
-// right-looking trailing update T(I,J) -= L(I,k) L(J,k)^T for every tile k < J <= I, and -- in the workgroup that owns
-// tile (k+1,k+1) -- straight on into gpcc_diag_body of step k+1 with the updated tile handed over in LDS (no global round
-// trip, no launch in between).  One evaluation's critical path is diag -> solve -> update of ONE tile -> diag ...; with
-// the diagonal step inside the update launch the rest of the trailing update runs beside it instead of before it:
-// launches per evaluation 3 nt - 2 -> 2 nt - 1.   grid cnt * n(n+1)/2 (n = nt-k-1), block 512, LDS = the diagonal image.
-// ------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(512) void gpcc_small_step(GpccCtx c, GpccGroup g, int k)
-{
-    typedef GpccPrec<T> P;
-    constexpr int CH = GPCC_CHUNK_BYTES / sizeof(T);
-    extern __shared__ __attribute__((aligned(16))) double smem_d[];
-    T *smem = (T *)smem_d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, q = lane >> 4;
-    const int sw = gpcc_sw(lr);
-    const int m = (int)blockIdx.x % g.cnt, j = (int)blockIdx.x / g.cnt;   // job j of evaluation m; j = 0 is tile (k+1,k+1)
-    const int slot = g.slot0 + m;
-    if (c.info[slot] != 0) {
-        if (j == 0) gpcc_diag_body<T, true>(c, g, k + 1, m, smem_d);   // (reports the failure on the last step, touches no LDS)
-        return;
-    }
-    int a = (int)((sqrtf(8.0f * j + 1.0f) - 1.0f) * 0.5f);
-    while (a * (a + 1) / 2 > j) --a;
-    while ((a + 1) * (a + 2) / 2 <= j) ++a;
-    const int I = k + 1 + a, J = k + 1 + (j - a * (a + 1) / 2);
-    T *tiles = (T *)c.tiles + (long)slot * c.slot_stride;
-    const T *gA = tiles + gpcc_tile_off(I, k), *gB = tiles + gpcc_tile_off(J, k);
-    T *Tt = tiles + gpcc_tile_off(I, J);
-    gpcc_dma_chunk<T>(gA, gB, smem, wave, lane);
-    if (j == 0) {   // tile (k+1,k+1): lower triangle only, then straight on into the diagonal step
-        switch (__builtin_amdgcn_readfirstlane(wave)) {
-        case 0: gpcc_small_diag_tile<T, 7, 0, 5, 0, 0, 0>(gA, gB, smem, Tt, smem_d, wave, lane); break;
-        case 1: gpcc_small_diag_tile<T, 6, 0, 5, 0, 0, 0>(gA, gB, smem, Tt, smem_d, wave, lane); break;
-        case 2: gpcc_small_diag_tile<T, 5, 0, 5, 0, 0, 0>(gA, gB, smem, Tt, smem_d, wave, lane); break;
-        case 3: gpcc_small_diag_tile<T, 4, 0, 5, 0, 0, 0>(gA, gB, smem, Tt, smem_d, wave, lane); break;
-        case 4: gpcc_small_diag_tile<T, 7, 5, 3, 0, 0, 1>(gA, gB, smem, Tt, smem_d, wave, lane); break;
-        case 5: gpcc_small_diag_tile<T, 6, 5, 2, 1, 0, 2>(gA, gB, smem, Tt, smem_d, wave, lane); break;
-        case 6: gpcc_small_diag_tile<T, 5, 5, 1, 2, 0, 3>(gA, gB, smem, Tt, smem_d, wave, lane); break;
-        default: gpcc_small_diag_tile<T, 3, 0, 4, 0, 0, 0>(gA, gB, smem, Tt, smem_d, wave, lane); break;
-        }
-        gpcc_diag_body<T, true>(c, g, k + 1, m, smem_d);
-        return;
-    }
-    typename P::acc_t acc[2][4];
-#pragma unroll
-    for (int fm = 0; fm < 2; ++fm)
-#pragma unroll
-        for (int fn = 0; fn < 4; ++fn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc[fm][fn][r] = -Tt[gpcc_elem_off<T>(wr * 32 + fm * 16 + P::crow(q, r), wc * 64 + fn * 16 + lr)];
-    const T *pa0 = smem + (wr * 32 + lr) * P::KC + (((2 * q) ^ sw) * P::EP);
-    const T *pa1 = smem + (wr * 32 + lr) * P::KC + (((2 * q + 1) ^ sw) * P::EP);
-    const T *pb0 = smem + CH + (wc * 64 + lr) * P::KC + (((2 * q) ^ sw) * P::EP);
-    const T *pb1 = smem + CH + (wc * 64 + lr) * P::KC + (((2 * q + 1) ^ sw) * P::EP);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll 2
-    for (int ch = 0; ch < P::NCH; ++ch) {   // one tile of K: the chunks of L(I,k) and L(J,k)
-        const int st = ch & 1;
-        if (ch + 1 < P::NCH)
-            gpcc_dma_chunk<T>(gA + (long)(ch + 1) * CH, gB + (long)(ch + 1) * CH, smem + (st ^ 1) * 2 * CH, wave, lane);
-        const int so = st * 2 * CH;
-        typename P::v16 av[2][2];
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            av[f][0] = *(const typename P::v16 *)(pa0 + so + f * 16 * P::KC);
-            av[f][1] = *(const typename P::v16 *)(pa1 + so + f * 16 * P::KC);
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            typename P::v16 b[2][2];
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                b[f][0] = *(const typename P::v16 *)(pb0 + so + (2 * h + f) * 16 * P::KC);
-                b[f][1] = *(const typename P::v16 *)(pb1 + so + (2 * h + f) * 16 * P::KC);
-            }
-#pragma unroll
-            for (int s = 0; s < P::KSTEPS; ++s)
-#pragma unroll
-                for (int fm = 0; fm < 2; ++fm)
-#pragma unroll
-                    for (int f = 0; f < 2; ++f)
-                        acc[fm][2 * h + f] = P::mfma(av[fm][s / P::EP][s % P::EP], b[f][s / P::EP][s % P::EP], acc[fm][2 * h + f]);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-#pragma unroll
-    for (int fm = 0; fm < 2; ++fm)
-#pragma unroll
-        for (int fn = 0; fn < 4; ++fn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                Tt[gpcc_elem_off<T>(wr * 32 + fm * 16 + P::crow(q, r), wc * 64 + fn * 16 + lr)] = -acc[fm][fn][r];
-}
-
-// ------------------------------------------------------------------------------------------
-// gpcc_syrk_diag (step k; companion of gpcc_update_solve): one workgroup per evaluation -- the lower triangle of the
-// diagonal tile, T'(k,k) = T(k,k) - sum_{j<k} L(k,j) L(k,j)^T (36 of 64 blocks, dealt to the waves like
-// gpcc_small_diag_tile; ONE operand stream: both MFMA operands are fragments of tile row k), through a 4-stage LDS ring
-// (one workgroup per CU: nothing else hides the load latency), then straight on into the diagonal step with the tile
-// handed over in LDS.  grid cnt, block 512, LDS = the diagonal image.
-// ------------------------------------------------------------------------------------------
+// The lower triangle of a diagonal tile -- 36 of its 64 16x16 blocks, all the diagonal step reads -- dealt 5/5/5/5/4/4/4/4 to the
+// eight waves (waves w and w+4 share a SIMD: one 5-block and one 4-block wave each): 56 % of the MFMA time of the full tile.
+// Wave-specialised: NA blocks (RA, CA..CA+NA-1) and NB blocks (RB, CB..CB+NB-1).  ONE operand stream (both MFMA operands are
+// fragments of the same tile row) through a 4-stage LDS ring with one barrier per chunk; the updated blocks (rounded to T, as the
+// unfused path stores them) end up in the diagonal step's LDS image.  Used by gpcc_small_step (K = one tile) and gpcc_syrk_diag.
 template <typename T, int RA, int CA, int NA, int RB, int CB, int NB>
 __device__ __forceinline__ void gpcc_syrk_lower_wave(const T *gRow, int nch, T *smem, const T *Tt, double *smem_d, int wave, int lane)
 {
@@ -1577,6 +1419,113 @@ __device__ __forceinline__ void gpcc_syrk_lower_wave(const T *gRow, int nch, T *
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// gpcc_small_step (step k of a group of a FEW evaluations, e.g. the single objective(alpha, rho) of Nelder-Mead): the
+// right-looking trailing update T(I,J) -= L(I,k) L(J,k)^T for every tile k < J <= I, and -- in the workgroup that owns
+// tile (k+1,k+1) -- straight on into gpcc_diag_body of step k+1 with the updated tile handed over in LDS (no global round
+// trip, no launch in between).  One evaluation's critical path is diag -> solve -> update of ONE tile -> diag ...; with
+// the diagonal step inside the update launch the rest of the trailing update runs beside it instead of before it:
+// launches per evaluation 3 nt - 2 -> 2 nt - 1.   grid cnt * n(n+1)/2 (n = nt-k-1), block 512, LDS = the diagonal image.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(512) void gpcc_small_step(GpccCtx c, GpccGroup g, int k)
+{
+    typedef GpccPrec<T> P;
+    constexpr int CH = GPCC_CHUNK_BYTES / sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) double smem_d[];
+    T *smem = (T *)smem_d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, q = lane >> 4;
+    const int sw = gpcc_sw(lr);
+    const int m = (int)blockIdx.x % g.cnt, j = (int)blockIdx.x / g.cnt;   // job j of evaluation m; j = 0 is tile (k+1,k+1)
+    const int slot = g.slot0 + m;
+    if (c.info[slot] != 0) {
+        if (j == 0) gpcc_diag_body<T, true>(c, g, k + 1, m, smem_d);   // (reports the failure on the last step, touches no LDS)
+        return;
+    }
+    int a = (int)((sqrtf(8.0f * j + 1.0f) - 1.0f) * 0.5f);
+    while (a * (a + 1) / 2 > j) --a;
+    while ((a + 1) * (a + 2) / 2 <= j) ++a;
+    const int I = k + 1 + a, J = k + 1 + (j - a * (a + 1) / 2);
+    T *tiles = (T *)c.tiles + (long)slot * c.slot_stride;
+    const T *gA = tiles + gpcc_tile_off(I, k), *gB = tiles + gpcc_tile_off(J, k);
+    T *Tt = tiles + gpcc_tile_off(I, J);
+    if (j == 0) {   // tile (k+1,k+1): lower triangle only (both operands are tile (k+1,k)), then straight on into the diagonal step
+        switch (__builtin_amdgcn_readfirstlane(wave)) {
+        case 0: gpcc_syrk_lower_wave<T, 7, 0, 5, 0, 0, 0>(gA, P::NCH, smem, Tt, smem_d, wave, lane); break;
+        case 1: gpcc_syrk_lower_wave<T, 6, 0, 5, 0, 0, 0>(gA, P::NCH, smem, Tt, smem_d, wave, lane); break;
+        case 2: gpcc_syrk_lower_wave<T, 5, 0, 5, 0, 0, 0>(gA, P::NCH, smem, Tt, smem_d, wave, lane); break;
+        case 3: gpcc_syrk_lower_wave<T, 4, 0, 5, 0, 0, 0>(gA, P::NCH, smem, Tt, smem_d, wave, lane); break;
+        case 4: gpcc_syrk_lower_wave<T, 7, 5, 3, 0, 0, 1>(gA, P::NCH, smem, Tt, smem_d, wave, lane); break;
+        case 5: gpcc_syrk_lower_wave<T, 6, 5, 2, 1, 0, 2>(gA, P::NCH, smem, Tt, smem_d, wave, lane); break;
+        case 6: gpcc_syrk_lower_wave<T, 5, 5, 1, 2, 0, 3>(gA, P::NCH, smem, Tt, smem_d, wave, lane); break;
+        default: gpcc_syrk_lower_wave<T, 3, 0, 4, 0, 0, 0>(gA, P::NCH, smem, Tt, smem_d, wave, lane); break;
+        }
+        gpcc_diag_body<T, true>(c, g, k + 1, m, smem_d);
+        return;
+    }
+    gpcc_dma_chunk<T>(gA, gB, smem, wave, lane);
+    typename P::acc_t acc[2][4];
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[fm][fn][r] = -Tt[gpcc_elem_off<T>(wr * 32 + fm * 16 + P::crow(q, r), wc * 64 + fn * 16 + lr)];
+    const T *pa0 = smem + (wr * 32 + lr) * P::KC + (((2 * q) ^ sw) * P::EP);
+    const T *pa1 = smem + (wr * 32 + lr) * P::KC + (((2 * q + 1) ^ sw) * P::EP);
+    const T *pb0 = smem + CH + (wc * 64 + lr) * P::KC + (((2 * q) ^ sw) * P::EP);
+    const T *pb1 = smem + CH + (wc * 64 + lr) * P::KC + (((2 * q + 1) ^ sw) * P::EP);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 2
+    for (int ch = 0; ch < P::NCH; ++ch) {   // one tile of K: the chunks of L(I,k) and L(J,k)
+        const int st = ch & 1;
+        if (ch + 1 < P::NCH)
+            gpcc_dma_chunk<T>(gA + (long)(ch + 1) * CH, gB + (long)(ch + 1) * CH, smem + (st ^ 1) * 2 * CH, wave, lane);
+        const int so = st * 2 * CH;
+        typename P::v16 av[2][2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            av[f][0] = *(const typename P::v16 *)(pa0 + so + f * 16 * P::KC);
+            av[f][1] = *(const typename P::v16 *)(pa1 + so + f * 16 * P::KC);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            typename P::v16 b[2][2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                b[f][0] = *(const typename P::v16 *)(pb0 + so + (2 * h + f) * 16 * P::KC);
+                b[f][1] = *(const typename P::v16 *)(pb1 + so + (2 * h + f) * 16 * P::KC);
+            }
+#pragma unroll
+            for (int s = 0; s < P::KSTEPS; ++s)
+#pragma unroll
+                for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+                        acc[fm][2 * h + f] = P::mfma(av[fm][s / P::EP][s % P::EP], b[f][s / P::EP][s % P::EP], acc[fm][2 * h + f]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Tt[gpcc_elem_off<T>(wr * 32 + fm * 16 + P::crow(q, r), wc * 64 + fn * 16 + lr)] = -acc[fm][fn][r];
+}
+
+// ------------------------------------------------------------------------------------------
+// gpcc_syrk_diag (step k; companion of gpcc_update_solve): one workgroup per evaluation -- the lower triangle of the
+// diagonal tile, T'(k,k) = T(k,k) - sum_{j<k} L(k,j) L(k,j)^T (36 of 64 blocks, dealt to the waves like
+// gpcc_syrk_lower_wave; ONE operand stream: both MFMA operands are fragments of tile row k), through a 4-stage LDS ring
+// (one workgroup per CU: nothing else hides the load latency), then straight on into the diagonal step with the tile
+// handed over in LDS.  grid cnt, block 512, LDS = the diagonal image.
+// ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(512) void gpcc_syrk_diag(GpccCtx c, GpccGroup g, int k)
 {
