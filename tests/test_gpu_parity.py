@@ -540,11 +540,17 @@ def test_baseline_size_goldens_fp64_and_fp32(gp, tags):
         for prec, tol in (("fp64", LL_RTOL), ("fp32", FP32_RTOL)):
             with gp.Objective(t, y, s, cs[0]["kernel"], marginalise_b=cs[0]["marginalise_b"], precision=prec,
                               slots_per_stream=8) as obj:
-                ll, info = obj.loglik_batch(*args)
-            assert (info == 0).all(), (key, prec, info)
-            err = _rel(ll, ref)
-            worst[prec] = max(worst[prec], err)
-            assert err <= tol, (cs[0]["tag"], cs[0]["kernel"], prec, err)
+                # a handful of evaluations take the small-group kernels (gpcc_small_step); right_looking_max = 0 sends the
+                # same batch down the left-looking path of the big sweeps (gpcc_syrk_diag + gpcc_update_solve, nt up to 128)
+                for rlm in (None, 0):
+                    if rlm is not None:
+                        obj.set_option("right_looking_max", rlm)
+                        obj.set_option("shared_prefix", 0)   # (identical band-1 parameters would otherwise select that mode's kernels)
+                    ll, info = obj.loglik_batch(*args)
+                    assert (info == 0).all(), (key, prec, rlm, info)
+                    err = _rel(ll, ref)
+                    worst[prec] = max(worst[prec], err)
+                    assert err <= tol, (cs[0]["tag"], cs[0]["kernel"], prec, rlm, err)
     print("%s vs LAPACK goldens: worst rel fp64 %.2e, fp32 %.2e" % ("/".join(tags), worst["fp64"], worst["fp32"]))
 
 
