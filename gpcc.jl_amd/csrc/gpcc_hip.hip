@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -1369,7 +1370,10 @@ extern "C" int gpcc_create_multi(gpcc_handle_t *out, int L, const int *Nl, const
     }
     h->device = device_ids[0];
     h->gather_mode = GPCC_GATHER_HOST;
-    if (distinct && n_devices > 1) {
+    // (GPCC_MULTI_FORCE_RCCL=1 takes the RCCL route also for a single device: a one-rank communicator -- how the one-GPU box
+    // exercises ncclCommInitAll / ncclAllGather / ncclCommDestroy of this library at all)
+    const char *force = getenv("GPCC_MULTI_FORCE_RCCL");
+    if (distinct && (n_devices > 1 || (force && force[0] == '1'))) {
         h->comms.assign(n_devices, nullptr);
         const ncclResult_t r = ncclCommInitAll(h->comms.data(), n_devices, device_ids);
         if (r != ncclSuccess) {

@@ -980,6 +980,27 @@ def test_multi_device_handle_matches_single_device(gp, oracle):
         gp.Objective(t, y, s, gp.matern32, devices=[0, 99])
 
 
+def test_multi_device_rccl_route_with_one_rank(gp, monkeypatch):
+    """The RCCL branch of the multi-device handle (ncclCommInitAll, ncclAllGather inside a group, ncclCommDestroy) needs
+    distinct devices; on a one-GPU box it can only run as a ONE-rank communicator (GPCC_MULTI_FORCE_RCCL=1).  That proves the
+    library's RCCL calls load, link and complete on the hardware -- not that a multi-rank gather is right."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([200, 180], seed=4)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    M = 9
+    delays = np.stack([np.zeros(M), np.linspace(0.0, 8.0, M)], 1)
+    with gp.Objective(t, y, s, gp.OU) as single:
+        ref, rinfo = single.loglik_batch(delays, np.tile(alpha, (M, 1)), np.full(M, rho))
+    monkeypatch.setenv("GPCC_MULTI_FORCE_RCCL", "1")
+    with gp.Objective(t, y, s, gp.OU, devices=[0]) as multi:
+        assert multi.get_option("gather_mode") == 1          # GPCC_GATHER_RCCL
+        for _ in range(2):
+            ll, info = multi.loglik_batch(delays, np.tile(alpha, (M, 1)), np.full(M, rho))
+            assert np.array_equal(ll, ref) and np.array_equal(info, rinfo)
+        gl, gi = multi.gathered(0)
+        assert np.array_equal(gl.ravel()[:M], ref)
+
+
 def test_torch_imported_after_the_library_shares_one_hip_runtime():
     """Round 1 saw "No HIP GPUs are available" when torch initialised the GPU AFTER libgpcc_hip.so had: two HIP/HSA
     runtimes in one process (gpcc_amd/_capi.py::_share_torch_rocm_runtime explains the loader rule).  A fresh process
