@@ -110,7 +110,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     backend = os.environ.get("GPCC_BENCH_BACKEND", "nccl")   # "nccl" = RCCL; "gloo" only for one-GPU rehearsals
-    if world > 1:
+    # GPCC_BENCH_FORCE_DIST=1: run the collective path also with ONE rank (a one-GPU box can then execute the RCCL branch --
+    # init_process_group("nccl"), all_gather_into_tensor, all_reduce, barrier -- as a one-rank group; launch under torchrun)
+    use_dist = world > 1 or os.environ.get("GPCC_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -152,7 +155,7 @@ def main():
 
     def step():
         obj.loglik_batch_device(d_delays, d_alpha, d_rho, out=d_ll, info=d_info)
-        if world > 1:
+        if use_dist:
             if backend == "nccl":
                 dist.all_gather_into_tensor(d_all, d_ll)     # the path's single collective (RCCL over xGMI)
             else:
@@ -167,7 +170,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -179,7 +182,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -286,7 +289,7 @@ def main():
         }
         print(json.dumps(out))
     obj.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()     # rank 0 is the last to arrive (roofline leg): leave the group together
         dist.destroy_process_group()
 
