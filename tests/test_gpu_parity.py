@@ -869,6 +869,13 @@ def test_handle_lifetimes_leave_no_device_memory_behind(gp):
                 obj.posterior_offsets([0.0, 2.0], alpha, rho)
                 obj.model_matrix([0.0, 2.0], alpha, rho)
                 obj.grid_loglik(d[:4], 3, rhomax=30.0)
+            if it % 2:   # fp32: an ill-conditioned evaluation makes the accuracy guard create (and the handle later free) its fp64 workspace
+                obj.loglik_batch(d[:2], np.tile(alpha * 60.0, (2, 1)), np.full(2, rho))
+                if it % 4 == 1:
+                    assert obj.get_option("fp32_guard_count") > 0
+        if it % 6 == 0:
+            with gp.Objective(t, y, s, "matern32", devices=[0, 0]) as multi:          # a multi-device handle: sub-handles, gather buffers
+                multi.loglik_batch(d, np.tile(alpha, (M, 1)), np.full(M, rho))
         gp.getprobabilities(np.zeros(10))
         gp.delayedCovariance("OU", [1.0, 1.0], [0.0, 1.0], 2.0, [t[0][:10], t[1][:10]])
         torch.cuda.synchronize()
