@@ -39,7 +39,7 @@ struct gpcc_handle_s {
     int streams = 1, slots_per_stream = 256, right_looking_max = GPCC_RIGHT_LOOKING_MAX;
     int fused_small_max = 12;  // groups of at most this many evaluations run gpcc_small_step (update + next diagonal step in one launch)
     int shared_prefix = 1;   // 0 off, 1 auto (host-pointer API detects it), 2 the caller asserts it
-    int update_t = 0;        // EXPERIMENT: transposed-accumulator update kernel
+    int update_t = 0;        // diagnostic option "update_t": the three-kernel path with gpcc_update_solve<T, false> as its update (A/B of the transposed main loop)
     int fused_solve = 1;     // option "fused_solve": left-looking groups run gpcc_syrk_diag + gpcc_update_solve (2 launches per step)
     int share_tiles = 0;     // tile rows wholly inside band 1
     bool share_now = false;  // decision for the batch being enqueued
