@@ -11,7 +11,9 @@ Weak scaling: the grid grows with the number of GPUs (1024 delays per GPU).
 
 Launch: python bench.py [--gpus 1]            or, for N > 1,
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-               --master-port P bench.py --gpus N --steps K --warmup W
+               --master-port P bench.py --gpus N --steps K --warmup W          (one process per GPU, RCCL via torch.distributed)
+        python bench.py --gpus N                                                 (no torchrun: ONE process, multi-device handle,
+                                                                                  RCCL all-gather inside libgpcc_hip.so)
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -70,6 +72,59 @@ def pmc_traffic(kernel, slots, N, prec="fp64"):
         return None, None
 
 
+def native_multi(args, ndev):
+    """python bench.py --gpus N without torchrun: weak scaling over a multi-device handle, host pointers in and out (the 40 KiB
+    of parameters per 1024 delays are part of the timed region).  GPCC_BENCH_OVERSUBSCRIBE=1 rehearses it on fewer GPUs
+    (repeated device ids gather through host memory instead of RCCL)."""
+    import gpcc_amd
+    from gpcc_amd import synthetic
+    N_ = args.gpus
+    if ndev >= N_:
+        devs = list(range(N_))
+    elif os.environ.get("GPCC_BENCH_OVERSUBSCRIBE") == "1":
+        devs = [i % ndev for i in range(N_)]
+    else:
+        raise SystemExit("--gpus %d without torchrun needs %d visible GPUs (found %d)" % (N_, N_, ndev))
+    Nb, L, G = args.n_per_band, args.bands, args.grid
+    t, y, s, _ = synthetic.simulate_lightcurves([Nb] * L, seed=args.seed)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    Gtot = G * N_
+    if L == 2:
+        delays = np.stack([np.zeros(Gtot), np.linspace(0.0, 20.0, Gtot)], 1)
+    else:
+        side = int(np.ceil(np.sqrt(Gtot)))
+        g1 = np.linspace(0.5, 6.0, side)
+        d2, d3 = np.meshgrid(g1, g1, indexing="ij")
+        delays = np.ascontiguousarray(np.stack([np.zeros(side * side), d2.ravel(), d3.ravel()], 1)[:Gtot])
+    alphas, rhos = np.tile(alpha, (Gtot, 1)), np.full(Gtot, float(rho))
+    with gpcc_amd.Objective(t, y, s, args.kernel, precision=args.precision, devices=devs, streams=args.streams,
+                            slots_per_stream=args.slots) as obj:
+        obj.set_option("shared_prefix", 0)
+        for kv in args.option:
+            key, val = kv.split("=")
+            obj.set_option(key, int(val))
+
+        def step():
+            ll, info = obj.loglik_batch(delays, alphas, rhos)       # sharded, ONE all-gather inside the library
+            return ll, info, gpcc_amd.getprobabilities(ll, device=devs[0])
+        for _ in range(args.warmup):
+            step()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ll, info, p = step()
+        elapsed = time.perf_counter() - t0
+        mode = {1: "rccl", 2: "host"}.get(obj.get_option("gather_mode"), "?")
+    print(json.dumps({
+        "metric": "delay-grid loglik evals/sec (N=%d, %d-band %s)" % (L * Nb, L, {"matern32": "Matern-3/2", "matern52": "Matern-5/2"}.get(args.kernel, args.kernel)),
+        "value": round(Gtot * args.steps / elapsed, 2), "unit": "evals/s", "n_gpus": N_, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64" if args.precision == "fp64" else "f32", "data": "synthetic",
+        "config": {"workload": "%d-band synthetic N=%d per band (N=%d), %s %s, %d-point delay grid per GPU" % (L, Nb, L * Nb, args.kernel, args.precision, G),
+                   "grid_total": Gtot, "devices": devs,
+                   "parallelism": "ONE process, multi-device handle x%d, 1 all-gather inside libgpcc_hip (%s)" % (N_, mode)},
+        "info_nonzero": int((info != 0).sum()), "posterior_sum": float(p.sum()), "roofline": None, "cpu_baseline": None}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,9 +157,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     gbuild.ensure_present(local)     # source-only checkout: compile libgpcc_hip.so once per node (hipcc, gfx950)
+    ndev = torch.cuda.device_count()
+    if world == 1 and args.gpus > 1:
+        # launched WITHOUT torchrun: ONE process drives the N GPUs through a multi-device handle (gpcc_create_multi: worker
+        # threads + the RCCL all-gather inside libgpcc_hip.so) -- the shape a Julia host uses
+        return native_multi(args, ndev)
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-    ndev = torch.cuda.device_count()
     if local >= ndev and os.environ.get("GPCC_BENCH_OVERSUBSCRIBE") == "1":
         local = local % ndev          # rehearsal only: several ranks on one GPU (gloo collective below)
     torch.cuda.set_device(local)
