@@ -40,6 +40,8 @@ struct gpcc_handle_s {
     int fused_small_max = 12;  // groups of at most this many evaluations run gpcc_small_step (update + next diagonal step in one launch)
     int shared_prefix = 1;   // 0 off, 1 auto (host-pointer API detects it), 2 the caller asserts it
     int update_t = 0;        // diagnostic option "update_t": the three-kernel path with gpcc_update_solve<T, false> as its update (A/B of the transposed main loop)
+    int fused_solve_min = 112;   // ... from this group size on (below it the diagonal tile's serial K-loop on ONE CU per evaluation costs
+                                 // more than the fused solve saves: measured crossover 96-128 evaluations at N = 1024 and N = 4096)
     int fused_solve = 1;     // option "fused_solve": left-looking groups run gpcc_syrk_diag + gpcc_update_solve (2 launches per step)
     int share_tiles = 0;     // tile rows wholly inside band 1
     bool share_now = false;  // decision for the batch being enqueued
@@ -315,6 +317,8 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->update_t = (int)v;
     } else if (!strcmp(key, "fused_solve")) {
         h->fused_solve = v != 0;
+    } else if (!strcmp(key, "fused_solve_min")) {
+        h->fused_solve_min = (int)v;
     } else if (!strcmp(key, "fp32_guard")) {
         h->fp32_guard = v != 0;
     } else if (!strcmp(key, "fp32_refine")) {
@@ -345,6 +349,7 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "bytes_per_slot")) return (long)(((long)h->nt * (h->nt + 1) / 2 + (h->precision ? h->nt : 1)) * GPCC_TILE_ELEMS) * (h->precision ? 4 : 8) + 16L * h->Np * h->nrhs;
     if (!strcmp(key, "precision")) return h->precision;
     if (!strcmp(key, "fused_solve")) return h->fused_solve;
+    if (!strcmp(key, "fused_solve_min")) return h->fused_solve_min;
     if (!strcmp(key, "fp32_guard")) return h->fp32_guard;
     if (!strcmp(key, "fp32_refine")) return h->fp32_refine;
     if (!strcmp(key, "fp32_guard_count")) return h->fb_count;
@@ -531,7 +536,7 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
         }
         return;
     }
-    if (!right && !p && c.nt_fact == c.nt && h->fused_solve && !c.store_l) {
+    if (!right && !p && c.nt_fact == c.nt && h->fused_solve && g.cnt >= h->fused_solve_min && !c.store_l) {
         // left-looking, the panel solve inside the update (gpcc_update_solve): per step the diagonal tile first
         // (gpcc_syrk_diag: lower-triangle update + diagonal step in one workgroup per evaluation), then the rest of column k
         for (int k = 0; k < c.nt; ++k) {

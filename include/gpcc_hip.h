@@ -85,6 +85,7 @@ int gpcc_multi_gathered(gpcc_handle_t handle, int which, long *blk_out, double *
  * trailing update of a step and the next diagonal step in ONE launch: the latency path of a single objective(alpha, rho)),
  * "fused_solve" (1 = default: left-looking groups run the panel solve inside the update kernel and the diagonal tile's update
  * inside the diagonal step -- two launches per step; 0 = the three-kernel path of round 1; results agree to ~1e-13),
+ * "fused_solve_min" (default 112: groups smaller than this keep the three-kernel path, which is faster there),
  * "shared_prefix" (0 off; 1 = default: gpcc_loglik_batch detects a
  * batch whose evaluations all have the same band-1 amplitude, delay and rho -- a fixed-hyper-parameter delay
  * sweep, README.md:172-174 -- and then factorises the tile rows wholly inside band 1 once per group instead of

@@ -546,6 +546,7 @@ def test_baseline_size_goldens_fp64_and_fp32(gp, tags):
                     if rlm is not None:
                         obj.set_option("right_looking_max", rlm)
                         obj.set_option("shared_prefix", 0)   # (identical band-1 parameters would otherwise select that mode's kernels)
+                        obj.set_option("fused_solve_min", 1) # (and small groups the three-kernel path)
                     ll, info = obj.loglik_batch(*args)
                     assert (info == 0).all(), (key, prec, rlm, info)
                     err = _rel(ll, ref)
@@ -905,6 +906,7 @@ def test_fused_solve_path_agrees_with_three_kernel_path(gp, oracle, Nl, prec, to
         with gp.Objective(t, y, s, gp.matern52, precision=prec, slots_per_stream=16) as obj:
             obj.set_option("right_looking_max", 0)    # left-looking also for the group of 3
             obj.set_option("shared_prefix", 0)
+            obj.set_option("fused_solve_min", 1)      # (by default only groups of >= 112 evaluations take the fused path)
             assert obj.get_option("fused_solve") == 1
             a, ia = obj.loglik_batch(delays, alphas, rhos)
             a2, ia2 = obj.loglik_batch(delays, alphas, rhos)

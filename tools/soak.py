@@ -49,6 +49,7 @@ while time.time() < t_end:
     try:
         with gp.Objective(t, y, s, kname, marginalise_b=mb, precision=prec, **opts) as obj:
             obj.set_option("right_looking_max", int(rng.choice([0, 8, 24, 64])))
+            obj.set_option("fused_solve_min", int(rng.choice([1, 8, 112])))     # fused update/solve path also for small left-looking groups
             ll, info = obj.loglik_batch(delays, alpha, rho)
             ll2, info2 = obj.loglik_batch(delays, alpha, rho)
             assert np.array_equal(ll, ll2, equal_nan=True) and np.array_equal(info, info2), "not repeatable"
