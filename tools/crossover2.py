@@ -11,6 +11,7 @@ for Nb in (512, 2048):
     with gpcc_amd.Objective(t, y, s, "matern32", slots_per_stream=256) as obj:
         obj.set_option("shared_prefix", 0)
         obj.set_option("right_looking_max", 0)
+        obj.set_option("fused_solve_min", 1)      # compare the two paths at every size (default: fused from 112 evaluations on)
         for M in (25, 32, 48, 64, 96, 128, 160, 192, 256):
             d = np.stack([np.zeros(M), np.linspace(0, 20, M)], 1); a = np.tile(alpha, (M, 1)); r = np.full(M, rho)
             res = []
