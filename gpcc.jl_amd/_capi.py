@@ -14,7 +14,7 @@ c_long_p = ctypes.POINTER(ctypes.c_long)
 
 KERNEL_IDS = {"OU": 0, "rbf": 1, "matern32": 2, "matern52": 3}
 PRECISION_IDS = {"fp64": 0, "fp32": 1}
-PROF_NAMES = ("assemble", "panel_update", "diag_factor", "panel_trsm", "refine", "small_step")
+PROF_NAMES = ("assemble", "panel_update", "diag_factor", "panel_trsm", "refine", "small_step", "small_eval")
 
 # every symbol include/gpcc_hip.h declares: name -> (restype, argtypes)
 BATCH_OBJECTIVE = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.POINTER(ctypes.c_long),

@@ -5,7 +5,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GPCC_HIP_LIB") or os.path.join(CSRC, "libgpcc_hip.so")
-_SOURCES = ["gpcc_hip.hip", "gpcc_kernels.hip.h", "gpcc_fit.h"]
+_SOURCES = ["gpcc_hip.hip", "gpcc_kernels.hip.h", "gpcc_small.hip.h", "gpcc_fit.h"]
 _HEADER = os.path.join(os.path.dirname(_HERE), "include", "gpcc_hip.h")
 
 

@@ -1,6 +1,7 @@
 // gpcc_hip.hip -- host side of libgpcc_hip.so: the C ABI of include/gpcc_hip.h over the gfx950
 // kernels of gpcc_kernels.hip.h.  No CPU fallback: every compute entry needs a HIP device.
 #include "gpcc_kernels.hip.h"
+#include "gpcc_small.hip.h"
 #include "gpcc_fit.h"
 
 #include "../../include/gpcc_hip.h"
@@ -43,6 +44,9 @@ struct gpcc_handle_s {
     int fused_solve_min = 112;   // ... from this group size on (below it the diagonal tile's serial K-loop on ONE CU per evaluation costs
                                  // more than the fused solve saves: measured crossover 96-128 evaluations at N = 1024 and N = 4096)
     int fused_solve = 1;     // option "fused_solve": left-looking groups run gpcc_syrk_diag + gpcc_update_solve (2 launches per step)
+    int small_n = 1;         // option "small_n": N <= GPCC_SMALL_MAXN runs gpcc_small_eval (one launch per batch, one wave per evaluation,
+                             // the matrix in registers; always fp64) instead of the tile kernels
+    long small_count = 0;    // evaluations that took that path so far ("small_n_count")
     int share_tiles = 0;     // tile rows wholly inside band 1
     bool share_now = false;  // decision for the batch being enqueued
     // workspace
@@ -201,6 +205,7 @@ extern "C" int gpcc_create(gpcc_handle_t *out, int L, const int *Nl, const doubl
     h->woodbury = (precision == GPCC_PRECISION_FP32 && marginalise_b) ? 1 : 0;
     h->nrhs = h->woodbury ? L + 1 : 1;
     h->share_tiles = (L >= 2) ? Nl[0] / GPCC_TILE : 0;
+    if (const char *e = getenv("GPCC_SMALL_N")) h->small_n = e[0] != '0';   // default of option "small_n" (A/B runs, tests of the tile kernels at small N)
     {   // default group size: 256 evaluations resident (one per CU in the diagonal step), capped at 64 GiB
         const double per_slot = ((double)h->nt * (h->nt + 1) / 2 + (precision ? h->nt : 1)) * GPCC_TILE_ELEMS * (precision ? 4.0 : 8.0) + 16.0 * h->Np * (L + 1);
         long cap = (long)(64.0 * 1024 * 1024 * 1024 / per_slot);
@@ -319,6 +324,8 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->fused_solve = v != 0;
     } else if (!strcmp(key, "fused_solve_min")) {
         h->fused_solve_min = (int)v;
+    } else if (!strcmp(key, "small_n")) {
+        h->small_n = v != 0;
     } else if (!strcmp(key, "fp32_guard")) {
         h->fp32_guard = v != 0;
     } else if (!strcmp(key, "fp32_refine")) {
@@ -350,6 +357,10 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "precision")) return h->precision;
     if (!strcmp(key, "fused_solve")) return h->fused_solve;
     if (!strcmp(key, "fused_solve_min")) return h->fused_solve_min;
+    if (!strcmp(key, "small_n")) return h->small_n;
+    if (!strcmp(key, "small_n_max")) return GPCC_SMALL_MAXN;
+    if (!strcmp(key, "small_n_active")) return (h->small_n && h->N <= GPCC_SMALL_MAXN) ? 1 : 0;
+    if (!strcmp(key, "small_n_count")) return h->small_count;
     if (!strcmp(key, "fp32_guard")) return h->fp32_guard;
     if (!strcmp(key, "fp32_refine")) return h->fp32_refine;
     if (!strcmp(key, "fp32_guard_count")) return h->fb_count;
@@ -589,11 +600,60 @@ static int enqueue_factor(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g,
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// The small-N family (gpcc_small.hip.h): N <= GPCC_SMALL_MAXN -- the sizes of the reference's own documentation (N = 110, 150,
+// README.md:156-287) -- is ONE launch per batch on the caller's stream: no workspace, no slots, no groups, no events.
+// ------------------------------------------------------------------------------------------
+static inline bool small_path(const gpcc_handle_t h) { return h->small_n && h->N <= GPCC_SMALL_MAXN; }
+
+template <int KID>
+static void launch_small_kid(int nb, const GpccCtx &c, const GpccGroup &g, hipStream_t s)
+{
+    switch (nb) {
+    case 1: gpcc_small_eval<1, KID><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 2: gpcc_small_eval<2, KID><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 3: gpcc_small_eval<3, KID><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 4: gpcc_small_eval<4, KID><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 5: gpcc_small_eval<5, KID><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 6: gpcc_small_eval<6, KID><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 7: gpcc_small_eval<7, KID><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 8: gpcc_small_eval<8, KID><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 9: gpcc_small_eval<9, KID><<<g.cnt, 64, 0, s>>>(c, g); break;
+    default: gpcc_small_eval<10, KID><<<g.cnt, 64, 0, s>>>(c, g); break;
+    }
+}
+
+static int enqueue_small(gpcc_handle_t h, int M, const double *d_delays, const double *d_alpha, const double *d_rho,
+                         double *d_loglik, int *d_info, hipStream_t caller)
+{
+    GpccCtx c = make_ctx(h);
+    c.nrhs = 1; c.woodbury = 0;   // the literal fp64 model whatever the handle's precision
+    GpccGroup g;
+    g.delays = d_delays; g.alpha = d_alpha; g.rho = d_rho;
+    g.out_loglik = d_loglik; g.out_info = d_info; g.out_cond = nullptr;
+    g.first = 0; g.slot0 = 0; g.cnt = M; g.spread = 0;
+    const int nb = (h->N + 1 + 15) / 16;   // the matrix bordered by the right-hand side, in 16 x 16 blocks
+    {
+        ProfScope pr(h, GPCC_PROF_SMALL_EVAL, caller);
+        switch (h->kernel_id) {
+        case 0: launch_small_kid<0>(nb, c, g, caller); break;
+        case 1: launch_small_kid<1>(nb, c, g, caller); break;
+        case 2: launch_small_kid<2>(nb, c, g, caller); break;
+        default: launch_small_kid<3>(nb, c, g, caller); break;
+        }
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, GPCC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    h->small_count += M;
+    return 0;
+}
+
 // M evaluations, device pointers, enqueued behind `caller` and joined back into it; d_cond (2 per evaluation, fp32
 // handles) may be NULL.  The calling thread holds the device.
 static int enqueue_batch(gpcc_handle_t h, int M, const double *d_delays, const double *d_alpha, const double *d_rho,
                          double *d_loglik, int *d_info, double *d_cond, hipStream_t caller)
 {
+    if (small_path(h)) return enqueue_small(h, M, d_delays, d_alpha, d_rho, d_loglik, d_info, caller);
     int rc = ensure_workspace(h);
     if (rc) return rc;
     if (!h->share_now) h->share_now = (h->shared_prefix == 2);   // device pointers cannot be inspected: only on assertion
@@ -736,7 +796,9 @@ extern "C" int gpcc_loglik_batch_device(gpcc_handle_t h, int M, const double *d_
     int rc = stream_on_device(h, stream, h->device);
     if (rc) return rc;
     hipStream_t caller = (hipStream_t)stream;
-    const bool f32 = h->precision == GPCC_PRECISION_FP32;
+    const bool small = small_path(h);
+    if (small && h->precision == GPCC_PRECISION_FP32) h->cond_host.assign(2 * (size_t)M, 0.0);   // evaluated in fp64: nothing to guard
+    const bool f32 = h->precision == GPCC_PRECISION_FP32 && !small;
     if (f32 && M > h->cond_cap) {
         hipFree(h->d_ocond);
         h->d_ocond = nullptr; h->cond_cap = 0;
