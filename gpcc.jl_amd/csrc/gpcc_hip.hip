@@ -67,6 +67,12 @@ struct gpcc_handle_s {
     double *d_par = nullptr, *d_out = nullptr, *d_ocond = nullptr;
     int *d_oinfo = nullptr;
     long par_cap = 0;
+    // small-N path, host-pointer API: pinned, device-mapped host buffers -- the kernel reads the parameters from them and
+    // writes loglik / info into them directly (zero-copy over PCIe: 8 (2L+1) bytes in, 12 bytes out per evaluation), so a
+    // call is pack + ONE launch + one stream synchronisation, without a single hipMemcpy
+    double *hp_par = nullptr, *hp_ll = nullptr;
+    int *hp_info = nullptr;
+    long hp_cap = 0;
     // fp32 mode: a-posteriori accuracy guard.  Every evaluation reports the sum and the maximum of
     // K_ii / d_i over its pivots; where the error model built on them exceeds the budget, the evaluation is repeated
     // on an internal fp64 handle (`fb`, created on first use) and its result replaces the fp32 one.
@@ -290,6 +296,9 @@ extern "C" int gpcc_destroy(gpcc_handle_t h)
     free_workspace(h);
     hipFree(h->d_t); hipFree(h->d_sig2); hipFree(h->d_resid); hipFree(h->d_band); hipFree(h->d_yv);
     hipFree(h->d_par); hipFree(h->d_out); hipFree(h->d_oinfo);
+    if (h->hp_par) hipHostFree(h->hp_par);
+    if (h->hp_ll) hipHostFree(h->hp_ll);
+    if (h->hp_info) hipHostFree(h->hp_info);
     hipFree(h->d_ocond); hipFree(h->d_fb_idx); hipFree(h->d_fb_par); hipFree(h->d_fb_out); hipFree(h->d_fb_info);
     if (h->fb) gpcc_destroy(h->fb);
     if (h->main_stream) hipStreamDestroy(h->main_stream);
@@ -610,16 +619,18 @@ template <int KID>
 static void launch_small_kid(int nb, const GpccCtx &c, const GpccGroup &g, hipStream_t s)
 {
     switch (nb) {
-    case 1: gpcc_small_eval<1, KID><<<g.cnt, 64, 0, s>>>(c, g); break;
-    case 2: gpcc_small_eval<2, KID><<<g.cnt, 64, 0, s>>>(c, g); break;
-    case 3: gpcc_small_eval<3, KID><<<g.cnt, 64, 0, s>>>(c, g); break;
-    case 4: gpcc_small_eval<4, KID><<<g.cnt, 64, 0, s>>>(c, g); break;
-    case 5: gpcc_small_eval<5, KID><<<g.cnt, 64, 0, s>>>(c, g); break;
-    case 6: gpcc_small_eval<6, KID><<<g.cnt, 64, 0, s>>>(c, g); break;
-    case 7: gpcc_small_eval<7, KID><<<g.cnt, 64, 0, s>>>(c, g); break;
-    case 8: gpcc_small_eval<8, KID><<<g.cnt, 64, 0, s>>>(c, g); break;
-    case 9: gpcc_small_eval<9, KID><<<g.cnt, 64, 0, s>>>(c, g); break;
-    default: gpcc_small_eval<10, KID><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 1: gpcc_small_eval<1, KID, 4><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 2: gpcc_small_eval<2, KID, 4><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 3: gpcc_small_eval<3, KID, 4><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 4: gpcc_small_eval<4, KID, 2><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 5: gpcc_small_eval<5, KID, 2><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 6: gpcc_small_eval<6, KID, 2><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 7: gpcc_small_eval<7, KID, 2><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 8: gpcc_small_eval<8, KID, 1><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 9: gpcc_small_eval<9, KID, 1><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 10: gpcc_small_eval<10, KID, 1><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 11: gpcc_small_eval<11, KID, 1><<<g.cnt, 64, 0, s>>>(c, g); break;
+    default: gpcc_small_eval<12, KID, 1><<<g.cnt, 64, 0, s>>>(c, g); break;
     }
 }
 
@@ -850,6 +861,21 @@ static int enqueue_host_batch(gpcc_handle_t h, int M, const double *delays, cons
     return rc;
 }
 
+static int ensure_pinned(gpcc_handle_t h, long M)
+{
+    if (M <= h->hp_cap) return 0;
+    if (h->hp_par) hipHostFree(h->hp_par);
+    if (h->hp_ll) hipHostFree(h->hp_ll);
+    if (h->hp_info) hipHostFree(h->hp_info);
+    h->hp_par = h->hp_ll = nullptr; h->hp_info = nullptr; h->hp_cap = 0;
+    const long cap = M < 1024 ? 1024 : M + M / 2;
+    HIPCHK(h, hipHostMalloc((void **)&h->hp_par, sizeof(double) * cap * (2 * h->L + 1), hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc((void **)&h->hp_ll, sizeof(double) * cap, hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc((void **)&h->hp_info, sizeof(int) * cap, hipHostMallocDefault));
+    h->hp_cap = cap;
+    return 0;
+}
+
 extern "C" int gpcc_loglik_batch(gpcc_handle_t h, int M, const double *delays, const double *alpha,
                                  const double *rho, double *loglik, int *info)
 {
@@ -859,6 +885,21 @@ extern "C" int gpcc_loglik_batch(gpcc_handle_t h, int M, const double *delays, c
     if (!delays || !alpha || !rho || !loglik || !info) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
     if (h->is_multi()) return multi_loglik_batch(h, M, delays, alpha, rho, loglik, info);
     GPCC_ON_DEVICE(h, h->device);
+    if (small_path(h)) {   // zero-copy: parameters read from, results written to pinned host memory by the kernel itself
+        int rc = ensure_pinned(h, M);
+        if (rc) return rc;
+        const long ML = (long)M * h->L;
+        memcpy(h->hp_par, delays, sizeof(double) * ML);
+        memcpy(h->hp_par + ML, alpha, sizeof(double) * ML);
+        memcpy(h->hp_par + 2 * ML, rho, sizeof(double) * M);
+        if (h->precision == GPCC_PRECISION_FP32) h->cond_host.assign(2 * (size_t)M, 0.0);   // evaluated in fp64: nothing to guard
+        rc = enqueue_small(h, M, h->hp_par, h->hp_par + ML, h->hp_par + 2 * ML, h->hp_ll, h->hp_info, h->main_stream);
+        if (rc) return rc;
+        HIPCHK(h, hipStreamSynchronize(h->main_stream));
+        memcpy(loglik, h->hp_ll, sizeof(double) * M);
+        memcpy(info, h->hp_info, sizeof(int) * M);
+        return 0;
+    }
     int rc = enqueue_host_batch(h, M, delays, alpha, rho, nullptr, nullptr);
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(loglik, h->d_out, sizeof(double) * M, hipMemcpyDeviceToHost, h->main_stream));

@@ -4,114 +4,193 @@
 // simulatedata.jl:119) -- in ONE launch per batch: assembly, Cholesky, forward substitution, log-determinant and the
 // Gaussian log-density, with the matrix never leaving the register file.
 //
-// One WAVE per evaluation.  The N x N matrix K, bordered by the right-hand side r = Y - bbar as row/column N (and identity
-// padding up to 16 NB), lives as the UPPER triangle of 16 x 16 blocks in MFMA accumulator layout: block (j, i), j <= i,
-// element [a][b] = K[16 j + a][16 i + b] sits in lane (lr = b, q = a & 3), register a >> 2  (v_mfma_f64_16x16x4_f64 C/D map:
-// row = q + 4 reg, col = lane & 15).  NB (NB + 1) / 2 blocks x 8 VGPRs: 224 registers at N = 110, 440 at N = 150 -- gfx950's
-// 512-entry unified VGPR/AGPR file is the largest on-chip store of a CU (512 KiB against 160 KiB of LDS).
+// One WAVE per evaluation.  The N x N matrix K, bordered by the right-hand side r = Y - bbar as its LAST row/column (index
+// 16 NB - 1; identity padding between N and it), is handled as the UPPER triangle of 16 x 16 blocks in MFMA accumulator
+// layout: block (j, i), j <= i, element [a][b] = K[16 j + a][16 i + b] sits in lane (lr = b, q = a & 3), register a >> 2
+// (v_mfma_f64_16x16x4_f64 C/D map: row = q + 4 reg, col = lane & 15).
 // Why that layout: an accumulator block X, as it sits in registers, is at the same time a valid MFMA B operand (B[k][col] with
 // k = its row index) and a valid A operand FOR ITS TRANSPOSE (A[row][k] = X[k][row]: lane (lr, q), k-step s holds X[q + 4 s][lr]
-// = its own register s).  The right-looking upper Cholesky  K = U'U  then needs no data movement at all outside the
-// 16 x 16 diagonal blocks:
-//     panel     U[jb][i]  = inv(L_D) K[jb][i]        (L_D = U[jb][jb]', lower)   A = inv(L_D) from LDS, B = block registers
-//     trailing  K[j][i]  -= U[jb][j]' U[jb][i]                                    A = B-side registers of two blocks
-// i.e. 4 MFMAs per block and step, operands straight from registers.  The blocks are kept NEGATED (S = -K) so that the
-// trailing update is a plain accumulation (no negated operand copies); the panel multiplies by -inv(L_D) instead.
-// Only the diagonal block takes the detour through LDS: 16 x 16 potf2 + triangular inverse in "lane owns a row / a column"
-// form (the register factorisation of gpcc_diag_body, gpcc_kernels.hip.h).
-// The right-hand side rides along as column N of the bordered matrix: after the last real pivot the Schur complement at
-// (N, N) is -w'w (w = L^-1 r) -- the quadratic form of Distributions.logpdf -- and the forward substitution is the same
-// MFMAs as the factorisation.  Pivot N is skipped (set to 1), padding pivots are 1: sum log L_ii is unchanged.
-//
-// Control flow: the block loops are DYNAMIC (one copy of the element code, one copy of the 16 x 16 factorisation) and
-// dispatch through switch statements to statically indexed register blocks -- a fully unrolled NB = 10 instance would be
-// ~80 KiB of code against a 64 KiB instruction cache.
+// = its own register s).  The upper Cholesky  K = U'U  then needs no data movement at all outside the 16 x 16 diagonal
+// blocks -- 4 MFMAs per block product, operands straight from registers:
+//     row j:  T[i] = -K[j][i]  (i >= j, assembled when the row is reached)     T[i] += sum_{m<j} U[m][j]' U[m][i]
+//             16 x 16 step on -T[j]  ->  -inv(L_D)   (L_D = U[j][j]')           U[j][i] = (-inv(L_D)) T[i]   (i > j)
+// (the "up-looking", row-by-row form; blocks are kept NEGATED so that the update is a plain accumulation, and the panel
+// multiplies by -inv(L_D) instead).  What is live between rows is the rectangle U[0..j][j+1..NB-1] -- (j+1)(NB-1-j) <= NB^2/4
+// blocks of 8 VGPRs instead of the whole triangle NB(NB+1)/2 a right-looking form keeps: 12 blocks (96 VGPRs) instead of 28 at
+// N = 110, 25 (200) instead of 55 at N = 150 -- so N <= 111 runs TWO waves per SIMD (f64 MFMAs issue every 64 cycles only when
+// two waves of a SIMD have some, profiles/r01/microbench_fp64.log; one wave alone: ~139) and N <= 191 fits the 512-entry unified
+// VGPR/AGPR file of one wave without scratch.  gfx950's register file (512 KiB per CU) is its largest on-chip store; LDS only
+// carries the staging of a row's elements, the point data and the 16 x 16 diagonal step.
+// Only the diagonal block takes a detour through LDS: 16 x 16 potf2 + triangular inverse in "lane owns a row / a column"
+// form (the register factorisation of gpcc_diag_body, gpcc_kernels.hip.h), software-pipelined by hand (the broadcast column
+// of pivot j is applied to columns >= j+2 during the reciprocal square root of pivot j+1) and fenced per pivot.
+// The right-hand side rides along as the last column: after the last real pivot its Schur complement is -w'w (w = L^-1 r)
+// -- the quadratic form of Distributions.logpdf -- and the forward substitution is the same MFMAs as the factorisation.
+// That pivot is skipped (set to 1), padding pivots are 1: sum log L_ii is unchanged.
+// (Round 3's first version kept the whole triangle in registers, right-looking, with dynamic block loops: 16.5 M evaluations/s
+// at N = 110 and 4.6 M/s with scratch spills at N = 150; this form: 30.4 and 11.4 M/s -- profiles/r03/.)
 #pragma once
 #include "gpcc_kernels.hip.h"
 
-#define GPCC_SMALL_MAXNB 10                      /* bordered size N + 1 <= 160 */
+#define GPCC_SMALL_MAXNB 12                      /* bordered size N + 1 <= 192 */
 #define GPCC_SMALL_MAXN (16 * GPCC_SMALL_MAXNB - 1)
 #define GPCC_SMALL_DLD 17
-#define GPCC_SMALL_STAGE 4                       /* blocks per assembly group (LDS staging: 2 KiB per block) */
 
-template <int NB>
-__host__ __device__ constexpr int gpcc_sblk(int j, int i)   // index of block (j, i), j <= i, in row-major upper order
+__device__ __forceinline__ void gpcc_small_potf2(const double *sD, double *sX, double *sr, const int lane, const bool last,
+                                                 const int base, double &py, int &pe, int &bad, double &quad)
 {
-    return j * NB - j * (j - 1) / 2 + (i - j);
-}
-
-// panel + trailing update of step JB on the statically indexed register blocks
-template <int NB, int JB>
-__device__ __forceinline__ void gpcc_small_update(d4 (&acc)[NB * (NB + 1) / 2], const double (&ax)[4])
-{
-    typedef GpccPrec<double> PD;
+    constexpr int DLD = GPCC_SMALL_DLD;
+    const int lr = lane & 15, q = lane >> 4;
+    double v[16], cn[16];
+    const double *row = sD + ((q != 0 ? 16 : 0) + lr) * DLD;   // L lanes: row lr of D; X lanes: row lr of the identity
 #pragma unroll
-    for (int i = JB + 1; i < NB; ++i) {   // U[JB][i] = (-inv(L_D)) S[JB][i]
-        d4 o = {0.0, 0.0, 0.0, 0.0};
+    for (int cc = 0; cc < 16; ++cc) { v[cc] = row[cc]; cn[cc] = 0.0; }
+    double d = gpcc_bcast(v[0], 0), vp = 0.0;
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) o = PD::mfma(ax[s], acc[gpcc_sblk<NB>(JB, i)][s], o);
-        acc[gpcc_sblk<NB>(JB, i)] = o;
+    for (int j = 0; j < 16; ++j) {
+        if (j == 15 && last) {   // the right-hand-side row: its Schur complement is -w'w; not a pivot
+            quad = -d;
+            d = 1.0;
+        }
+        if (!(d > 0.0) && bad == 0) bad = base + j + 1;   // also catches NaN
+        const double y = gpcc_rsqrt(d);
+        if (j >= 1) {   // the rest of pivot j-1's rank-1 update (column j had its share through the readlane below)
+#pragma unroll
+            for (int cc = j + 1; cc < 16; ++cc) v[cc] = __builtin_fma(-vp, cn[cc], v[cc]);
+        }
+        py *= __builtin_amdgcn_frexp_mant(y);
+        pe += __builtin_amdgcn_frexp_exp(y);
+        v[j] *= y;
+        if (j < 15) {
+            sr[q == 0 ? lr : 16 + lane] = v[j];   // column j of L_D -> LDS (the other lanes store to a dead area: no branch)
+            const double lnx = gpcc_bcast(v[j], j + 1);
+            v[j + 1] = __builtin_fma(-v[j], lnx, v[j + 1]);
+            d = gpcc_bcast(v[j + 1], j + 1);
+            vp = v[j];
+#pragma unroll
+            for (int cc = j + 2; cc < 16; ++cc) cn[cc] = sr[cc];
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
+    pe += __builtin_amdgcn_frexp_exp(py);   // renormalise the running product once per block
+    py = __builtin_amdgcn_frexp_mant(py);
+    if (q == 1) {   // -inv(L_D), row-major: sX[row cc][col l]
 #pragma unroll
-    for (int i = JB + 1; i < NB; ++i)
-#pragma unroll
-        for (int j = JB + 1; j <= i; ++j)   // S[j][i] += U[JB][j]' U[JB][i]
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                acc[gpcc_sblk<NB>(j, i)] = PD::mfma(acc[gpcc_sblk<NB>(JB, j)][s], acc[gpcc_sblk<NB>(JB, i)][s], acc[gpcc_sblk<NB>(j, i)]);
-}
-
-// run-time step / group index -> the statically indexed code for it (a compare chain; the register blocks stay scalars)
-template <int NB, int JB>
-__device__ __forceinline__ void gpcc_small_dispatch_update(int jb, d4 (&acc)[NB * (NB + 1) / 2], const double (&ax)[4])
-{
-    if constexpr (JB < NB - 1) {
-        if (jb == JB) gpcc_small_update<NB, JB>(acc, ax);
-        else gpcc_small_dispatch_update<NB, JB + 1>(jb, acc, ax);
-    }
-}
-template <int NB, int JB>
-__device__ __forceinline__ d4 gpcc_small_dispatch_diag(int jb, const d4 (&acc)[NB * (NB + 1) / 2])
-{
-    if constexpr (JB < NB - 1) {
-        if (jb == JB) return acc[gpcc_sblk<NB>(JB, JB)];
-        return gpcc_small_dispatch_diag<NB, JB + 1>(jb, acc);
-    } else {
-        return acc[gpcc_sblk<NB>(NB - 1, NB - 1)];
+        for (int cc = 0; cc < 16; ++cc) sX[cc * DLD + lr] = -v[cc];
     }
 }
-// group G of the assembly: blocks 4 G .. 4 G + 3 from the LDS stage into their registers
-template <int NB, int G>
-__device__ __forceinline__ void gpcc_small_stage_load(int grp, d4 (&acc)[NB * (NB + 1) / 2], const double *stage, int lane)
+
+// everything a row needs besides the register blocks (all scalarised after inlining)
+struct GpccSmallState {
+    const double *su, *sa, *ssb;
+    const int *sbd;
+    double *sstage, *sD, *sX, *sr;
+    const double *sig2, *resid;
+    GpccKernelConst kc;
+    int N, lane;
+    double py, quad;   // prod of the mantissas of 1 / sqrt(d_j); r' K^-1 r
+    int pe, bad;       // sum of their exponents; order of the first non-positive pivot
+};
+
+// rows J .. NB-1 by compile-time recursion (a `#pragma unroll` of this loop is refused beyond ~16k IR instructions)
+template <int NB, int KID, int J>
+__device__ __forceinline__ void gpcc_small_rows(d4 (&U)[NB][NB], GpccSmallState &st)
 {
-    constexpr int NBLK = NB * (NB + 1) / 2, NGRP = (NBLK + GPCC_SMALL_STAGE - 1) / GPCC_SMALL_STAGE;
-    if constexpr (G < NGRP) {
-        if (grp == G) {
+    if constexpr (J < NB) {
+        typedef GpccPrec<double> PD;
+        constexpr int NP = 16 * NB, DLD = GPCC_SMALL_DLD;
+        constexpr int SB = (NB + 1) / 2;   // blocks per staging pass (a row is assembled in at most two)
+        const int lane = st.lane, lr = lane & 15, q = lane >> 4, N = st.N;
+        d4 T[NB];
+        // ---- (a) row J of S = -(K bordered): blocks (J, i), i >= J, through the LDS stage
 #pragma unroll
-            for (int s = 0; s < GPCC_SMALL_STAGE; ++s)
-                if (GPCC_SMALL_STAGE * G + s < NBLK) {
+        for (int i0 = J; i0 < NB; i0 += SB) {
+            const int i1 = (i0 + SB < NB) ? i0 + SB : NB;
+#pragma nounroll
+            for (int i = i0; i < i1; ++i) {
+                const int gc = 16 * i + lr;
+                const double uc = st.su[gc], ac = st.sa[gc];
+                const int bc = st.sbd[gc];
+                const bool edge = 16 * i + 15 >= N;   // the block holds the right-hand side and/or padding (wave-uniform)
+                double val[4];
+                int br[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[GPCC_SMALL_STAGE * G + s][r] = stage[(s * 4 + r) * 64 + lane];
+                for (int r = 0; r < 4; ++r) {
+                    const int gr = 16 * J + q + 4 * r;
+                    br[r] = st.sbd[gr];
+                    const double kv = gpcc_kernel_eval<KID>(st.su[gr], uc, st.kc);   // kernel(x - delays[i], y - delays[j]; rho)
+                    val[r] = (st.sa[gr] * ac) * kv;                                  // scale[i] scale[j] kernel, delayedCovariance.jl:27
                 }
-        } else {
-            gpcc_small_stage_load<NB, G + 1>(grp, acc, stage, lane);
+                if (i == J) {   // (wave-uniform) + Sobs, marginaliseb.jl:89, :135; padding: 1, right-hand-side row: 0
+                    const double sgc = gc < N ? st.sig2[gc] : (gc == NP - 1 ? 0.0 : 1.0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (q + 4 * r == lr) val[r] = val[r] + sgc;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)   // + B = Q Sigma_b Q' (same band), marginaliseb.jl:96, :135
+                    val[r] = val[r] + ((br[r] == bc && bc >= 0) ? st.ssb[gc] : 0.0);
+                if (edge) {     // (wave-uniform) the last column = Y - bbar, and its mirror inside the last diagonal block
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int gr = 16 * J + q + 4 * r;
+                        if (bc == -3 && br[r] >= 0) val[r] = st.resid[gr];
+                        if (br[r] == -3 && bc >= 0) val[r] = st.resid[gc];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st.sstage[((i - i0) * 4 + r) * 64 + lane] = -val[r];
+            }
+#pragma unroll
+            for (int i = i0; i < i1; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T[i][r] = st.sstage[((i - i0) * 4 + r) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- (b) T[i] += sum_{m<J} U[m][J]' U[m][i]
+#pragma unroll
+        for (int i = J; i < NB; ++i)
+#pragma unroll
+            for (int mm = 0; mm < J; ++mm)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) T[i] = PD::mfma(U[mm][J][s], U[mm][i][s], T[i]);
+        // ---- (c) the diagonal block: 16 x 16 potf2 + inverse
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st.sD[(q + 4 * r) * DLD + lr] = -T[J][r];
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        gpcc_small_potf2(st.sD, st.sX, st.sr, lane, J == NB - 1, 16 * J, st.py, st.pe, st.bad, st.quad);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st.bad) return;
+        if constexpr (J < NB - 1) {
+            // ---- (d) U[J][i] = (-inv(L_D)) T[i]
+            __syncthreads();
+            double ax[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ax[s] = st.sX[lr * DLD + q + 4 * s];
+#pragma unroll
+            for (int i = J + 1; i < NB; ++i) {
+                d4 o = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) o = PD::mfma(ax[s], T[i][s], o);
+                U[J][i] = o;
+            }
+            __syncthreads();   // sD / sX are rewritten by the next row
+            __builtin_amdgcn_sched_barrier(0);
+            gpcc_small_rows<NB, KID, J + 1>(U, st);
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// gpcc_small_eval<NB, KID>: one wave = one evaluation (tau, alpha, rho) -> loglik, info.
-// grid = number of evaluations, block = 64.  Needs no workspace: reads the handle's light curves, writes the outputs.
-// ------------------------------------------------------------------------------------------
-template <int NB, int KID>
-__global__ __launch_bounds__(64) void gpcc_small_eval(GpccCtx c, GpccGroup g)
+template <int NB, int KID, int WPE>
+__global__ __launch_bounds__(64, WPE) void gpcc_small_eval(GpccCtx c, GpccGroup g)
 {
-    typedef GpccPrec<double> PD;
-    constexpr int NBLK = NB * (NB + 1) / 2, NP = 16 * NB, DLD = GPCC_SMALL_DLD;
-    constexpr int NGRP = (NBLK + GPCC_SMALL_STAGE - 1) / GPCC_SMALL_STAGE;
+    constexpr int NP = 16 * NB, DLD = GPCC_SMALL_DLD;
+    constexpr int SB = (NB + 1) / 2;
     const int m = blockIdx.x;
     if (m >= g.cnt) return;
-    const int lane = threadIdx.x & 63, lr = lane & 15, q = lane >> 4;
+    const int lane = threadIdx.x & 63;
     const int N = c.N;
     const double *delays = g.delays + (long)(g.first + m) * c.L;
     const double *alpha = g.alpha + (long)(g.first + m) * c.L;
@@ -129,125 +208,39 @@ __global__ __launch_bounds__(64) void gpcc_small_eval(GpccCtx c, GpccGroup g)
             return;
         }
     }
-    const GpccKernelConst kc = gpcc_kernel_const<KID>(rho);
-
-    __shared__ double su[NP], sa[NP], ssb[NP], ssg[NP], sres[NP];   // shifted time, amplitude, Sigma_b of the band, sigma^2 (diagonal add), Y - bbar
-    __shared__ int sbd[NP];                                          // band id; -1 padding; -3 the right-hand-side row
-    __shared__ double sstage[GPCC_SMALL_STAGE * 4 * 64];
-    __shared__ double sD[32 * DLD], sX[16 * DLD], sr[96];   // sD rows 16..31: the identity (start values of the inverse's columns)
+    __shared__ double su[NP], sa[NP], ssb[NP];   // shifted time, amplitude, Sigma_b of the band
+    __shared__ int sbd[NP];                       // band id; -1 padding; -3 the right-hand-side row
+    __shared__ double sstage[SB * 4 * 64];
+    __shared__ double sD[32 * DLD], sX[16 * DLD], sr[96];   // sD rows 16..31: the identity
 
     const bool mb = c.marginalise_b != 0;
     for (int p = lane; p < NP; p += 64) {
         int b = -1;
-        double u = 0.0, a = 0.0, sb = 0.0, sg = 1.0, rs = 0.0;   // padding: identity
+        double u = 0.0, a = 0.0, sb = 0.0;
         if (p < N) {
             b = c.band[p];
             u = c.t[p] - delays[b];            // x - delays[i], delayedCovariance.jl:27
             a = alpha[b];
             sb = mb ? c.sigma_b[b] : 0.0;      // B = Q Sigma_b Q', marginaliseb.jl:96, :135
-            sg = c.sig2[p];                    // Sobs, :89
-            rs = c.resid[p];                   // Y - bbar
-        } else if (p == NP - 1) {   // the right-hand side: always the LAST row / column (local pivot 15 of the last block)
+        } else if (p == NP - 1) {              // the right-hand side: always the LAST row / column (local pivot 15 of the last block)
             b = -3;
-            sg = 0.0;
         }
-        sbd[p] = b; su[p] = u; sa[p] = a; ssb[p] = sb; ssg[p] = sg; sres[p] = rs;
+        sbd[p] = b; su[p] = u; sa[p] = a; ssb[p] = sb;
     }
     for (int e = lane; e < 16 * DLD; e += 64) sD[16 * DLD + e] = (e / DLD == e % DLD) ? 1.0 : 0.0;
     __syncthreads();
 
-    // ---- assembly: S = -(K bordered), block by block in row-major upper order, four blocks per group
-    d4 acc[NBLK];
-    {
-        int j = 0, i = 0;
-#pragma nounroll
-        for (int grp = 0; grp < NGRP; ++grp) {
-#pragma nounroll
-            for (int s = 0; s < GPCC_SMALL_STAGE; ++s) {
-                if (GPCC_SMALL_STAGE * grp + s >= NBLK) break;
-                const int gc = 16 * i + lr;
-                const double uc = su[gc], ac = sa[gc];
-                const int bc = sbd[gc];
-                const bool edge = 16 * i + 15 >= N;   // the block holds the right-hand side and/or padding (wave-uniform)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gr = 16 * j + q + 4 * r;
-                    const int br = sbd[gr];
-                    const double kv = gpcc_kernel_eval<KID>(su[gr], uc, kc);   // kernel(x - delays[i], y - delays[j]; rho)
-                    double val = (sa[gr] * ac) * kv;                           // scale[i] scale[j] kernel, delayedCovariance.jl:27
-                    if (i == j && gr == gc) val = val + ssg[gr];               // + Sobs  (padding: 1, right-hand-side row: 0)
-                    val = val + ((br == bc && br >= 0) ? ssb[gr] : 0.0);       // + B (same band)
-                    if (edge) {
-                        if (bc == -3 && br >= 0) val = sres[gr];               // last column = Y - bbar
-                        if (br == -3 && bc >= 0) val = sres[gc];               // (its mirror inside the last diagonal block)
-                    }
-                    sstage[(s * 4 + r) * 64 + lane] = -val;
-                }
-                if (++i == NB) { ++j; i = j; }
-            }
-            gpcc_small_stage_load<NB, 0>(grp, acc, sstage, lane);
-        }
-    }
-
-    // ---- right-looking blocked Cholesky (upper form) with the right-hand side as column N
-    double py = 1.0, quad = 0.0;        // prod of the mantissas of 1 / sqrt(d_j), and r' K^-1 r
-    int pe = 0, bad = 0;                // sum of their exponents; order of the first non-positive pivot
-#pragma nounroll
-    for (int jb = 0; jb < NB; ++jb) {
-        const bool last = jb == NB - 1;
-        {
-            const d4 dg = gpcc_small_dispatch_diag<NB, 0>(jb, acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sD[(q + 4 * r) * DLD + lr] = -dg[r];
-        }
-        __syncthreads();
-        {
-            // 16 x 16 potf2 + inverse in registers.  Lanes 0-15: lane l owns row l of D (v[cc] = D[l][cc]); lanes 16-31:
-            // lane 16 + l owns column l of X = inv(L_D) (v[cc] = delta(cc, l) - sum_j L[cc][j] X[j][l]); lanes 32-63 shadow
-            // them.  Right-looking, one instruction stream for both (see gpcc_diag_body).
-            double v[16];
-            const double *row = sD + ((q != 0 ? 16 : 0) + lr) * DLD;   // (X lanes: a row of the identity, through the same loads)
-#pragma unroll
-            for (int cc = 0; cc < 16; ++cc) v[cc] = row[cc];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                double d = gpcc_bcast(v[j], j);
-                if (j == 15 && last) {   // the right-hand-side row: its Schur complement is -w'w; not a pivot
-                    quad = -d;
-                    d = 1.0;
-                }
-                if (!(d > 0.0) && bad == 0) bad = 16 * jb + j + 1;   // also catches NaN
-                const double y = gpcc_rsqrt(d);
-                py *= __builtin_amdgcn_frexp_mant(y);
-                pe += __builtin_amdgcn_frexp_exp(y);
-                v[j] *= y;
-                if (j < 15) {
-                    sr[q == 0 ? lr : 16 + lane] = v[j];   // column j of L_D -> LDS (the other lanes store to a dead area: no branch)
-                    const double lnx = gpcc_bcast(v[j], j + 1);
-                    v[j + 1] = __builtin_fma(-v[j], lnx, v[j + 1]);
-#pragma unroll
-                    for (int cc = j + 2; cc < 16; ++cc) v[cc] = __builtin_fma(-v[j], sr[cc], v[cc]);
-                }
-            }
-            pe += __builtin_amdgcn_frexp_exp(py);   // renormalise the running product once per block
-            py = __builtin_amdgcn_frexp_mant(py);
-            if (q == 1) {   // -inv(L_D), row-major: sX[row cc][col l]
-#pragma unroll
-                for (int cc = 0; cc < 16; ++cc) sX[cc * DLD + lr] = -v[cc];
-            }
-        }
-        if (bad || last) break;
-        __syncthreads();
-        double ax[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) ax[s] = sX[lr * DLD + q + 4 * s];
-        gpcc_small_dispatch_update<NB, 0>(jb, acc, ax);
-    }
+    GpccSmallState st;
+    st.su = su; st.sa = sa; st.ssb = ssb; st.sbd = sbd; st.sstage = sstage; st.sD = sD; st.sX = sX; st.sr = sr;
+    st.sig2 = c.sig2; st.resid = c.resid; st.kc = gpcc_kernel_const<KID>(rho); st.N = N; st.lane = lane;
+    st.py = 1.0; st.quad = 0.0; st.pe = 0; st.bad = 0;
+    d4 U[NB][NB];   // finished rows: U[m][i], i > m
+    gpcc_small_rows<NB, KID, 0>(U, st);
     if (lane == 0) {
         // logpdf(MvNormal(bbar, K), Y) = -(N log 2pi + logdet K) / 2 - (Y - bbar)' K^-1 (Y - bbar) / 2   (marginaliseb.jl:139)
         const double log2pi = 1.8378770664093454835606594728112;
-        const double ld = -(log(py) + (double)pe * 0.69314718055994530942);   // sum log L_ii
-        g.out_loglik[g.first + m] = bad ? __builtin_nan("") : -((double)N * log2pi + 2.0 * ld) / 2.0 - quad / 2.0;
-        g.out_info[g.first + m] = bad;
+        const double ld = -(log(st.py) + (double)st.pe * 0.69314718055994530942);   // sum log L_ii
+        g.out_loglik[g.first + m] = st.bad ? __builtin_nan("") : -((double)N * log2pi + 2.0 * ld) / 2.0 - st.quad / 2.0;
+        g.out_info[g.first + m] = st.bad;
     }
 }

@@ -215,7 +215,7 @@ enum {
     GPCC_PROF_TRSM = 3,         /* gpcc_panel_trsm         -- fp64 MFMA */
     GPCC_PROF_REFINE = 4,       /* fp32 mode: backward solve + X' K0 X + final arithmetic */
     GPCC_PROF_SMALL_STEP = 5,   /* gpcc_small_step: trailing update + next diagonal step in one launch (a few evaluations) */
-    GPCC_PROF_SMALL_EVAL = 6,   /* gpcc_small_eval: a whole evaluation (assembly + Cholesky + solve) of N <= 159 points in one wave */
+    GPCC_PROF_SMALL_EVAL = 6,   /* gpcc_small_eval: a whole evaluation (assembly + Cholesky + solve) of N <= 191 points in one wave */
     GPCC_PROF_COUNT = 7
 };
 int gpcc_profile_enable(gpcc_handle_t handle, int on);

@@ -24,7 +24,7 @@ def gp():
 
 @pytest.fixture(autouse=True, params=["tile", "small"])
 def kernel_family(request, monkeypatch):
-    """Every test of this module runs twice: N <= 159 on the tile kernels (GPCC_SMALL_N=0: assembly + diagonal-block kernels,
+    """Every test of this module runs twice: N <= 191 on the tile kernels (GPCC_SMALL_N=0: assembly + diagonal-block kernels,
     the only path of rounds 1-2) and on the small-N family (gpcc_small_eval: one wave per evaluation, the default).  Larger N
     take the tile kernels either way."""
     monkeypatch.setenv("GPCC_SMALL_N", "0" if request.param == "tile" else "1")

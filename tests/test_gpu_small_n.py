@@ -30,12 +30,12 @@ def _params(rng, M, L):
     return delays, rng.uniform(0.4, 3.0, (M, L)), rng.uniform(0.5, 8.0, M)
 
 
-def test_small_path_is_the_default_up_to_159_points(gp):
+def test_small_path_is_the_default_up_to_191_points(gp):
     rng = np.random.default_rng(1)
-    for n, active in ((1, 1), (110, 1), (150, 1), (159, 1), (160, 0), (300, 0)):
+    for n, active in ((1, 1), (110, 1), (150, 1), (159, 1), (160, 1), (191, 1), (192, 0), (300, 0)):
         t, y, s = _problem(rng, [n])
         with gp.Objective(t, y, s, "OU", marginalise_b=False) as obj:
-            assert obj.get_option("small_n_max") == 159
+            assert obj.get_option("small_n_max") == 191
             assert obj.get_option("small_n_active") == active, n
             obj.loglik_batch(np.zeros((3, 1)), np.ones((3, 1)), np.full(3, 2.0))
             assert obj.get_option("small_n_count") == (3 if active else 0)
@@ -43,12 +43,12 @@ def test_small_path_is_the_default_up_to_159_points(gp):
             assert obj.get_option("small_n_active") == 0
 
 
-def test_every_size_1_to_159_vs_oracle_and_tile_path(gp, oracle):
-    """All totals N = 1 .. 159 (every 16-block count, every position of the last real row inside its block), 1-3 bands,
+def test_every_size_1_to_191_vs_oracle_and_tile_path(gp, oracle):
+    """All totals N = 1 .. 191 (every 16-block count, every position of the last real row inside its block), 1-3 bands,
     all kernels, both b-modes: small-N kernel == oracle (1e-9) and == the tile kernels (1e-11)."""
     rng = np.random.default_rng(7)
     worst_o = worst_t = 0.0
-    for N in range(1, 160):
+    for N in range(1, 192):
         L = 1 + (N % 3) if N >= 6 else 1
         mb = bool(N % 2) and N >= 2 * L
         cuts = np.sort(rng.choice(np.arange(2, N - 1), L - 1, replace=False)) if L > 1 else np.array([], dtype=int)
@@ -68,7 +68,7 @@ def test_every_size_1_to_159_vs_oracle_and_tile_path(gp, oracle):
         worst_o = max(worst_o, np.max(np.abs(ll - ref) / np.abs(ref)))
         worst_t = max(worst_t, np.max(np.abs(ll - ll_t) / np.abs(ll_t)))
         assert worst_o <= 1e-9 and worst_t <= 1e-11, (N, Nl, kname, mb, worst_o, worst_t)
-    print("N = 1..159: worst vs oracle %.2e, worst vs tile kernels %.2e" % (worst_o, worst_t))
+    print("N = 1..191: worst vs oracle %.2e, worst vs tile kernels %.2e" % (worst_o, worst_t))
 
 
 def test_golden_cases_on_the_small_path(gp, golden):
