@@ -19,11 +19,15 @@
 #include <limits>
 #include <vector>
 
+#include "gpcc_transforms.h"
+
 namespace gpccfit {
 
-inline double makepositive(double x) { return x > 30.0 ? x : log1p(exp(x)); }
+// the forward transforms are shared with the device (bit-identical on both sides, gpcc_transforms.h); the inverses only
+// prepare the random start candidates on the host
+inline double makepositive(double x) { return gpcctf::makepositive(x); }
 inline double invmakepositive(double y) { return y > 30.0 ? y : log(expm1(y)); }
-inline double transformbetween(double x, double a, double b) { return a + (b - a) / (1.0 + exp(-x)); }
+inline double transformbetween(double x, double a, double b) { return gpcctf::transformbetween(x, a, b); }
 inline double invtransformbetween(double y, double a, double b)
 {
     const double u = (y - a) / (b - a);
@@ -84,6 +88,13 @@ struct BatchedNelderMead {
     double g_tol;
     long long f_calls = 0, rounds = 0;
     std::vector<int> it;
+    // Speculative rounds (latency-bound fits: a README-size grid is 100-200 problems, a few per cent of the chip): the
+    // expansion and both contraction points depend on the centroid and the reflected point only, not on f(reflected), so a
+    // round of at most `speculate_max` requests evaluates all four candidates of an iteration at once and the decision
+    // tree of Optim's loop is walked on the host afterwards -- ~1.6 dependent rounds per iteration become ~1.  Every problem
+    // makes exactly the decisions it makes without speculation (same points, same values: needs an objective whose value
+    // does not depend on the composition of the batch, which holds for the small-N kernels); f_calls counts the extra work.
+    long speculate_max = 0;
 
     BatchedNelderMead(long P_, int n_, int iterations_, double g_tol_) : P(P_), n(n_), iterations(iterations_), g_tol(g_tol_) {}
 
@@ -177,6 +188,12 @@ struct BatchedNelderMead {
             if (!any) break;
             pid.clear();
             X.clear();
+            long nreflect = 0, nother = 0;
+            for (long p = 0; p < P; ++p) {
+                nreflect += req[p] == REFLECT;
+                nother += (req[p] == SHRINK) ? n : (req[p] != REFLECT && req[p] != DONE);
+            }
+            const bool spec = nreflect > 0 && 4 * nreflect + nother <= speculate_max;
             // requests, grouped by phase (problems ascending inside a group)
             for (long p = 0; p < P; ++p)
                 if (req[p] == REFLECT) {
@@ -185,6 +202,18 @@ struct BatchedNelderMead {
                     for (int d = 0; d < n; ++d) xr[(size_t)p * n + d] = c[d] + alpha * (c[d] - xh[d]);
                     push(p, &xr[(size_t)p * n]);
                 }
+            const long spec_base = (long)pid.size();   // speculative requests: 3 per reflecting problem (expand, outside, inside)
+            if (spec)
+                for (long p = 0; p < P; ++p)
+                    if (req[p] == REFLECT) {
+                        const double *c = &cen[(size_t)p * n], *r = &xr[(size_t)p * n];
+                        for (int ph = EXPAND; ph <= INSIDE; ++ph) {
+                            for (int d = 0; d < n; ++d)
+                                tmp[d] = ph == EXPAND ? c[d] + beta * (r[d] - c[d])
+                                       : ph == OUTSIDE ? c[d] + gamma * (r[d] - c[d]) : c[d] - gamma * (r[d] - c[d]);
+                            push(p, tmp.data());
+                        }
+                    }
             for (int ph = EXPAND; ph <= INSIDE; ++ph)
                 for (long p = 0; p < P; ++p)
                     if (req[p] == ph) {
@@ -214,6 +243,33 @@ struct BatchedNelderMead {
             // answers, in request order
             long pos = 0;
             std::fill(finished.begin(), finished.end(), 0);
+            auto second = [&](long p, int ph, double v, const double *x) {   // answer to an expansion / contraction request
+                int *o = &order[(size_t)p * n1];
+                double *f = &fs[(size_t)p * n1];
+                if (ph == EXPAND) {
+                    const int hi = o[n];
+                    const bool better = v < fr[p];
+                    double *dst = vert(p, hi);
+                    for (int d = 0; d < n; ++d) dst[d] = better ? x[d] : xr[(size_t)p * n + d];
+                    f[hi] = better ? v : fr[p];
+                    for (int j = n; j > 0; --j) o[j] = o[j - 1];   // the new point is the lowest
+                    o[0] = hi;
+                    phase[p] = REFLECT;
+                    finished[p] = 1;
+                } else {
+                    const bool ok = ph == OUTSIDE ? v < fr[p] : v < f[o[n]];
+                    if (ok) {
+                        double *dst = vert(p, o[n]);
+                        for (int d = 0; d < n; ++d) dst[d] = x[d];
+                        f[o[n]] = v;
+                        sortperm(f, n1, o);
+                        phase[p] = REFLECT;
+                        finished[p] = 1;
+                    } else
+                        phase[p] = SHRINK;
+                }
+            };
+            long kspec = 0;
             for (long p = 0; p < P; ++p)
                 if (req[p] == REFLECT) {
                     const double v = fv[pos++];
@@ -229,37 +285,23 @@ struct BatchedNelderMead {
                         finished[p] = 1;
                     } else if (v < f[o[n]]) phase[p] = OUTSIDE;
                     else phase[p] = INSIDE;
+                    if (spec) {   // the follow-up request was evaluated in this very round
+                        const long q0 = spec_base + 3 * kspec++;
+                        if (!finished[p]) {
+                            const int ph = phase[p];
+                            const long q = q0 + (ph - EXPAND);
+                            second(p, ph, fv[q], &X[(size_t)q * n]);
+                        }
+                    }
                 }
+            if (spec) pos = spec_base + 3 * nreflect;
             for (int ph = EXPAND; ph <= INSIDE; ++ph)
                 for (long p = 0; p < P; ++p)
                     if (req[p] == ph) {
                         const double v = fv[pos];
                         const double *x = &X[(size_t)pos * n];
                         ++pos;
-                        int *o = &order[(size_t)p * n1];
-                        double *f = &fs[(size_t)p * n1];
-                        if (ph == EXPAND) {
-                            const int hi = o[n];
-                            const bool better = v < fr[p];
-                            double *dst = vert(p, hi);
-                            for (int d = 0; d < n; ++d) dst[d] = better ? x[d] : xr[(size_t)p * n + d];
-                            f[hi] = better ? v : fr[p];
-                            for (int j = n; j > 0; --j) o[j] = o[j - 1];   // the new point is the lowest
-                            o[0] = hi;
-                            phase[p] = REFLECT;
-                            finished[p] = 1;
-                        } else {
-                            const bool ok = ph == OUTSIDE ? v < fr[p] : v < f[o[n]];
-                            if (ok) {
-                                double *dst = vert(p, o[n]);
-                                for (int d = 0; d < n; ++d) dst[d] = x[d];
-                                f[o[n]] = v;
-                                sortperm(f, n1, o);
-                                phase[p] = REFLECT;
-                                finished[p] = 1;
-                            } else
-                                phase[p] = SHRINK;
-                        }
+                        second(p, ph, v, x);
                     }
             {
                 const long base = pos;

@@ -71,8 +71,12 @@ struct gpcc_handle_s {
     // writes loglik / info into them directly (zero-copy over PCIe: 8 (2L+1) bytes in, 12 bytes out per evaluation), so a
     // call is pack + ONE launch + one stream synchronisation, without a single hipMemcpy
     double *hp_par = nullptr, *hp_ll = nullptr;
-    int *hp_info = nullptr;
+    int *hp_info = nullptr, *hp_row = nullptr;
     long hp_cap = 0;
+    double *d_cand = nullptr;   // gpcc_grid_loglik: the candidate-delay table (G x L) on the device
+    long cand_cap = 0;
+    int fit_speculate = 1;      // option "fit_speculate": speculative optimiser rounds on the small-N path (gpcc_fit.h)
+    int fit_device_unpack = 1;  // option "fit_device_unpack": the small-N kernel unpacks the optimiser's vectors itself
     // fp32 mode: a-posteriori accuracy guard.  Every evaluation reports the sum and the maximum of
     // K_ii / d_i over its pivots; where the error model built on them exceeds the budget, the evaluation is repeated
     // on an internal fp64 handle (`fb`, created on first use) and its result replaces the fp32 one.
@@ -299,6 +303,8 @@ extern "C" int gpcc_destroy(gpcc_handle_t h)
     if (h->hp_par) hipHostFree(h->hp_par);
     if (h->hp_ll) hipHostFree(h->hp_ll);
     if (h->hp_info) hipHostFree(h->hp_info);
+    if (h->hp_row) hipHostFree(h->hp_row);
+    hipFree(h->d_cand);
     hipFree(h->d_ocond); hipFree(h->d_fb_idx); hipFree(h->d_fb_par); hipFree(h->d_fb_out); hipFree(h->d_fb_info);
     if (h->fb) gpcc_destroy(h->fb);
     if (h->main_stream) hipStreamDestroy(h->main_stream);
@@ -335,6 +341,10 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->fused_solve_min = (int)v;
     } else if (!strcmp(key, "small_n")) {
         h->small_n = v != 0;
+    } else if (!strcmp(key, "fit_speculate")) {
+        h->fit_speculate = v != 0;
+    } else if (!strcmp(key, "fit_device_unpack")) {
+        h->fit_device_unpack = v != 0;
     } else if (!strcmp(key, "fp32_guard")) {
         h->fp32_guard = v != 0;
     } else if (!strcmp(key, "fp32_refine")) {
@@ -367,6 +377,8 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "fused_solve")) return h->fused_solve;
     if (!strcmp(key, "fused_solve_min")) return h->fused_solve_min;
     if (!strcmp(key, "small_n")) return h->small_n;
+    if (!strcmp(key, "fit_speculate")) return h->fit_speculate;
+    if (!strcmp(key, "fit_device_unpack")) return h->fit_device_unpack;
     if (!strcmp(key, "small_n_max")) return GPCC_SMALL_MAXN;
     if (!strcmp(key, "small_n_active")) return (h->small_n && h->N <= GPCC_SMALL_MAXN) ? 1 : 0;
     if (!strcmp(key, "small_n_count")) return h->small_count;
@@ -634,8 +646,11 @@ static void launch_small_kid(int nb, const GpccCtx &c, const GpccGroup &g, hipSt
     }
 }
 
+// d_xpar != NULL: requests of the optimiser (M x (L+1) unconstrained vectors, unpacked on the device; d_delays is then the
+// candidate-delay table and d_xrow[i] the row of evaluation i)
 static int enqueue_small(gpcc_handle_t h, int M, const double *d_delays, const double *d_alpha, const double *d_rho,
-                         double *d_loglik, int *d_info, hipStream_t caller)
+                         double *d_loglik, int *d_info, hipStream_t caller, const double *d_xpar = nullptr,
+                         const int *d_xrow = nullptr, double rhomin = 0.0, double rhomax = 0.0)
 {
     GpccCtx c = make_ctx(h);
     c.nrhs = 1; c.woodbury = 0;   // the literal fp64 model whatever the handle's precision
@@ -643,6 +658,7 @@ static int enqueue_small(gpcc_handle_t h, int M, const double *d_delays, const d
     g.delays = d_delays; g.alpha = d_alpha; g.rho = d_rho;
     g.out_loglik = d_loglik; g.out_info = d_info; g.out_cond = nullptr;
     g.first = 0; g.slot0 = 0; g.cnt = M; g.spread = 0;
+    g.xpar = d_xpar; g.xrow = d_xrow; g.rhomin = rhomin; g.rhomax = rhomax;
     const int nb = (h->N + 1 + 15) / 16;   // the matrix bordered by the right-hand side, in 16 x 16 blocks
     {
         ProfScope pr(h, GPCC_PROF_SMALL_EVAL, caller);
@@ -867,11 +883,13 @@ static int ensure_pinned(gpcc_handle_t h, long M)
     if (h->hp_par) hipHostFree(h->hp_par);
     if (h->hp_ll) hipHostFree(h->hp_ll);
     if (h->hp_info) hipHostFree(h->hp_info);
-    h->hp_par = h->hp_ll = nullptr; h->hp_info = nullptr; h->hp_cap = 0;
+    if (h->hp_row) hipHostFree(h->hp_row);
+    h->hp_par = h->hp_ll = nullptr; h->hp_info = h->hp_row = nullptr; h->hp_cap = 0;
     const long cap = M < 1024 ? 1024 : M + M / 2;
     HIPCHK(h, hipHostMalloc((void **)&h->hp_par, sizeof(double) * cap * (2 * h->L + 1), hipHostMallocDefault));
     HIPCHK(h, hipHostMalloc((void **)&h->hp_ll, sizeof(double) * cap, hipHostMallocDefault));
     HIPCHK(h, hipHostMalloc((void **)&h->hp_info, sizeof(int) * cap, hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc((void **)&h->hp_row, sizeof(int) * cap, hipHostMallocDefault));
     h->hp_cap = cap;
     return 0;
 }
@@ -1311,13 +1329,33 @@ struct FitEval {
     double rhomin, rhomax;
     std::vector<double> delays, alpha, rho, ll;
     std::vector<int> info;
+    bool device_unpack = false;   // single-device small-N handle: the kernel unpacks the optimiser's vectors (fit_eval_small)
 };
+
+// the small-N route of an optimiser round: X and the delay rows go to pinned memory as they are, the kernel unpacks
+static int fit_eval_small(gpcc_handle_t h, const FitEval &e, long K, const long *pidx, const double *X, double *f)
+{
+    GPCC_ON_DEVICE(h, h->device);
+    int rc = ensure_pinned(h, K);
+    if (rc) return rc;
+    const int n = e.L + 1;
+    memcpy(h->hp_par, X, sizeof(double) * K * n);
+    for (long i = 0; i < K; ++i) h->hp_row[i] = (int)(pidx[i] / e.R);
+    rc = enqueue_small(h, (int)K, h->d_cand, nullptr, nullptr, h->hp_ll, h->hp_info, h->main_stream, h->hp_par, h->hp_row,
+                       e.rhomin, e.rhomax);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->main_stream));
+    for (long i = 0; i < K; ++i)   // safewrapper(negativeobjective), :149-153: a failed evaluation is +Inf
+        f[i] = h->hp_info[i] == 0 ? -h->hp_ll[i] : std::numeric_limits<double>::infinity();
+    return 0;
+}
 
 int fit_eval(void *vctx, long K, const long *pidx, const double *X, double *f)
 {
     FitEval &e = *static_cast<FitEval *>(vctx);
     const int L = e.L;
     if (K > 0x7fffffffL) return fail(e.h, GPCC_ERR_ARGUMENT, "optimiser round of %ld evaluations", K);
+    if (e.device_unpack) return fit_eval_small(e.h, e, K, pidx, X, f);
     e.delays.resize(K * L); e.alpha.resize(K * L); e.rho.resize(K); e.ll.resize(K); e.info.resize(K);
     for (long i = 0; i < K; ++i)
         for (int l = 0; l < L; ++l) e.delays[i * L + l] = e.cand[(pidx[i] / e.R) * L + l];
@@ -1354,6 +1392,18 @@ extern "C" int gpcc_grid_loglik(gpcc_handle_t h, int G, const double *delays, in
         gpccfit::initial_params(L, R, C, rhomin, rhomax, seed, vary, cands.data());
     }
     FitEval ev{h, delays, R, L, rhomin, rhomax, {}, {}, {}, {}, {}};
+    const bool small_fit = !h->is_multi() && small_path(h);
+    if (small_fit && h->fit_device_unpack) {   // the candidate-delay table lives on the device for the duration of the fit
+        GPCC_ON_DEVICE(h, h->device);
+        if ((long)G * L > h->cand_cap) {
+            hipFree(h->d_cand);
+            h->d_cand = nullptr; h->cand_cap = 0;
+            HIPCHK(h, hipMalloc(&h->d_cand, sizeof(double) * (size_t)G * L));
+            h->cand_cap = (long)G * L;
+        }
+        HIPCHK(h, hipMemcpy(h->d_cand, delays, sizeof(double) * (size_t)G * L, hipMemcpyHostToDevice));
+        ev.device_unpack = true;
+    }
 
     // the best of the random candidates starts each problem (:209); problem p = (delay p / R, restart p % R) and
     // every delay sees the same candidates (each reference gpcc call seeds its own generator with `seed`)
@@ -1373,6 +1423,9 @@ extern "C" int gpcc_grid_loglik(gpcc_handle_t h, int G, const double *delays, in
         memcpy(&x0[p * n], &X[(p * C + best) * n], sizeof(double) * n);
     }
     gpccfit::BatchedNelderMead nm(P, n, iterations, 1e-6);            // Optim.Options(iterations, g_tol = 1e-6), :205
+    // small-N kernels: an evaluation's value does not depend on what else is in the batch, and up to ~4 waves per CU
+    // cost no more time than one -- so latency-bound rounds evaluate the whole decision tree of an iteration at once
+    if (small_fit && h->fit_speculate) nm.speculate_max = 1024;
     std::vector<double> xmin((size_t)P * n), fmin(P);
     rc = nm.run(fit_eval, &ev, x0.data(), xmin.data(), fmin.data());
     if (rc) return rc;

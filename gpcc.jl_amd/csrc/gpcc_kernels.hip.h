@@ -101,6 +101,13 @@ struct GpccGroup {
     int cnt;    // evaluations in this group
     int spread; // fewer than 8 evaluations: job b -> (evaluation b % cnt, tile b / cnt), i.e. every evaluation's tiles
                 // go round all 8 XCDs instead of staying on the one XCD that blockIdx % 8 selects (set by the host)
+    // small-N kernels only -- requests of the optimiser in its own coordinates (gpcc_grid_loglik): xpar != NULL means
+    // evaluation i has the unconstrained parameter vector xpar[i][0..L], unpacked ON THE DEVICE (`unpack`,
+    // marginaliseb.jl:112-126: alpha = makepositive(x[1:L]) + 1e-8, rho = transformbetween(x[L+1], rhomin, rhomax),
+    // gpcc_transforms.h) and the delay vector delays[xrow[i]][0..L-1] (a row of the candidate-delay table)
+    const double *xpar = nullptr;
+    const int *xrow = nullptr;
+    double rhomin = 0.0, rhomax = 0.0;
 };
 
 __device__ __forceinline__ long gpcc_tile_off(int I, int J)

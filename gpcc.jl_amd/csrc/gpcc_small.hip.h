@@ -31,6 +31,7 @@
 // at N = 110 and 4.6 M/s with scratch spills at N = 150; this form: 30.4 and 11.4 M/s -- profiles/r03/.)
 #pragma once
 #include "gpcc_kernels.hip.h"
+#include "gpcc_transforms.h"
 
 #define GPCC_SMALL_MAXNB 12                      /* bordered size N + 1 <= 192 */
 #define GPCC_SMALL_MAXN (16 * GPCC_SMALL_MAXNB - 1)
@@ -192,13 +193,24 @@ __global__ __launch_bounds__(64, WPE) void gpcc_small_eval(GpccCtx c, GpccGroup 
     if (m >= g.cnt) return;
     const int lane = threadIdx.x & 63;
     const int N = c.N;
-    const double *delays = g.delays + (long)(g.first + m) * c.L;
-    const double *alpha = g.alpha + (long)(g.first + m) * c.L;
-    const double rho = g.rho[g.first + m];
+    __shared__ double sal[GPCC_MAXL];   // the amplitudes of this evaluation
+    const double *delays;
+    double rho;
+    if (g.xpar) {   // a request of the optimiser: unpack here (bit-identical to the host's gpcc_unpack_params)
+        const double *x = g.xpar + (long)(g.first + m) * (c.L + 1);
+        delays = g.delays + (long)g.xrow[g.first + m] * c.L;
+        if (lane < c.L) sal[lane] = gpcctf::makepositive(x[lane]) + 1e-8;          // makeα, marginaliseb.jl:112
+        rho = gpcctf::transformbetween(x[c.L], g.rhomin, g.rhomax);                // makeρ, :114
+    } else {
+        delays = g.delays + (long)(g.first + m) * c.L;
+        if (lane < c.L) sal[lane] = g.alpha[(long)(g.first + m) * c.L + lane];
+        rho = g.rho[g.first + m];
+    }
+    __syncthreads();
     {   // the reference's argument checks (delayedCovariance.jl:3, :5-7)
         int badarg = 0;
         for (int l = 0; l < c.L; ++l)
-            if (!(alpha[l] > 0.0)) badarg = -1;
+            if (!(sal[l] > 0.0)) badarg = -1;
         if (badarg == 0 && rho <= 0.0) badarg = -2;
         if (badarg) {
             if (lane == 0) {
@@ -220,7 +232,7 @@ __global__ __launch_bounds__(64, WPE) void gpcc_small_eval(GpccCtx c, GpccGroup 
         if (p < N) {
             b = c.band[p];
             u = c.t[p] - delays[b];            // x - delays[i], delayedCovariance.jl:27
-            a = alpha[b];
+            a = sal[b];
             sb = mb ? c.sigma_b[b] : 0.0;      // B = Q Sigma_b Q', marginaliseb.jl:96, :135
         } else if (p == NP - 1) {              // the right-hand side: always the LAST row / column (local pivot 15 of the last block)
             b = -3;

@@ -445,6 +445,7 @@ def test_native_grid_fit_equals_python_host_logic(gp, oracle):
         rng = np.random.default_rng(5)
         cand = np.concatenate([np.zeros((9, 1)), rng.uniform(0.0, 8.0, (9, L - 1))], axis=1)
         with gp.Objective(t, y, s, kern) as obj:
+            obj.set_option("fit_speculate", 0)   # (the numpy mirror makes the plain requests; speculation: test_gpu_small_n.py)
             nat = fit.gpcc_grid(t, y, s, kernel=kern, candidatedelays=cand, iterations=iters, numberofrestarts=R,
                                 rhomax=30.0, objective=obj, engine="native")
             py = fit.gpcc_grid(t, y, s, kernel=kern, candidatedelays=cand, iterations=iters, numberofrestarts=R,

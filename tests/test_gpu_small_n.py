@@ -196,3 +196,56 @@ def test_readme_sweep_fit_matches_the_tile_path(gp):
     assert np.max(np.abs(a[0] - b[0]) / np.abs(b[0])) <= 1e-6
     p = gp.getprobabilities(a[0])
     assert abs(grid[int(np.argmax(p))] - 2.0) <= 0.4 + 1e-9
+
+
+def test_fit_device_unpack_and_speculative_rounds_change_no_bit(gp):
+    """gpcc_grid_loglik on the small-N path: (a) the kernel unpacking the optimiser's vectors itself (gpcc_transforms.h on
+    the device) gives the same bits as the host unpacking them (same header on the host); (b) speculative rounds (all four
+    candidate points of an iteration evaluated at once) walk exactly the trajectory of the plain rounds: every output
+    identical, fewer rounds, more evaluations."""
+    from gpcc_amd import synthetic
+    for Nl, kern, R in (([60, 50], "matern32", 1), ([60, 50, 40], "OU", 2)):
+        L = len(Nl)
+        t, y, s, _ = synthetic.simulate_lightcurves(Nl, seed=1, gap_band=1, span=20.0)
+        rng = np.random.default_rng(9)
+        cand = np.concatenate([np.zeros((23, 1)), rng.uniform(0.0, 8.0, (23, L - 1))], axis=1)
+        res = {}
+        with gp.Objective(t, y, s, kern) as obj:
+            for spec, dev in ((0, 0), (0, 1), (1, 1), (1, 0)):
+                obj.set_option("fit_speculate", spec)
+                obj.set_option("fit_device_unpack", dev)
+                res[spec, dev] = obj.grid_loglik(cand, 150, numberofrestarts=R, rhomax=100.0, seed=3)
+        base = res[0, 0]
+        assert (base[3] == 0).all()
+        for key, r in res.items():
+            assert all(np.array_equal(u, v) for u, v in zip(r[:5], base[:5])), key
+        assert res[0, 1][5] == base[5]                       # same evaluations, same rounds
+        assert res[1, 1][5] == res[1, 0][5]
+        (fc0, rd0), (fc1, rd1) = base[5], res[1, 1][5]
+        print("%s: plain %d evaluations in %d rounds; speculative %d in %d" % (Nl, fc0, rd0, fc1, rd1))
+        assert rd1 < 0.8 * rd0 and fc1 > fc0
+
+
+def test_unpack_on_the_device_is_bitwise_the_hosts(gp):
+    """One evaluation per parameter vector through the optimiser-request form of the kernel (device unpack) against
+    gpcc_unpack_params (host) + the plain form: identical bits, including extreme arguments of the transforms."""
+    from gpcc_amd import api, synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([30, 25], seed=2, span=20.0)
+    rng = np.random.default_rng(4)
+    X = np.concatenate([rng.uniform(-6, 6, (300, 3)), rng.uniform(-40, 45, (200, 3)),
+                        np.array([[31.0, -700.0, 0.0], [-30.0, 30.0, 40.0], [0.0, 0.0, -38.0]])])
+    alpha, rho = api.unpack_params(X, 2, 0.1, 300.0)
+    assert np.all(alpha > 0) and np.all(rho >= 0.1) and np.all(rho <= 300.0)
+    cand = np.array([[0.0, 1.5]])
+    with gp.Objective(t, y, s, "matern32") as obj:
+        ll, info = obj.loglik_batch(np.repeat(cand, len(X), 0), alpha, rho)
+        # iterations = 0: the fit evaluates the candidates (through the device unpack), then the affine simplex + its centroid
+        for i in range(0, len(X), 50):
+            a = obj.grid_loglik(cand, 0, initialrandom=50, rhomin=0.1, rhomax=300.0, init_params=X[i:i + 50][None, :, :]) if i + 50 <= len(X) else None
+            if a is None:
+                continue
+            obj.set_option("fit_device_unpack", 0)
+            b = obj.grid_loglik(cand, 0, initialrandom=50, rhomin=0.1, rhomax=300.0, init_params=X[i:i + 50][None, :, :])
+            obj.set_option("fit_device_unpack", 1)
+            assert all(np.array_equal(u, v) for u, v in zip(a[:5], b[:5])), i
+    assert np.isfinite(ll[info == 0]).all()

@@ -192,3 +192,20 @@ def test_unpack_params_matches_numpy_transforms():
     with np.errstate(over="ignore"):
         np.testing.assert_allclose(rho, fit.transformbetween(X[:, 3], 0.1, 300.0), rtol=1e-14)
     assert np.all(alpha > 0) and np.all((rho >= 0.1) & (rho <= 300.0))
+
+
+def test_shared_transforms_within_four_ulp_of_libm():
+    """gpcc_transforms.h (the exp / log the host AND the device unpack with): softplus and the logistic map against numpy
+    (libm) over the whole range an optimiser can reach, incl. the branches x > 30, exp(x) below an ulp of 1, overflow."""
+    from gpcc_amd import api
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-745, 709, 20000), rng.uniform(-40, 40, 20000), rng.uniform(-2, 2, 20000),
+                        np.array([-800.0, -745.0, -37.0, -36.0, 0.0, 29.999, 30.0, 30.001, 709.0, 800.0])])
+    X = np.stack([x, x], 1)
+    alpha, rho = api.unpack_params(X, 1, 0.1, 300.0)
+    sp = np.where(x > 30.0, x, np.log1p(np.exp(np.minimum(x, 30.0)))) + 1e-8
+    with np.errstate(over="ignore"):
+        lg = 0.1 + (300.0 - 0.1) / (1.0 + np.exp(-x))
+    assert np.all(np.abs(alpha[:, 0] - sp) <= 4 * np.spacing(sp))
+    assert np.all(np.abs(rho - lg) <= 4 * np.spacing(lg))
+    assert np.all(alpha > 0) and rho.min() >= 0.1 and rho.max() <= 300.0
