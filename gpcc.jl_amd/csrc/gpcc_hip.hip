@@ -13,7 +13,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -24,6 +26,27 @@
 static thread_local std::string g_err;
 
 struct ProfRec { int which; hipEvent_t a, b; };
+
+// small-N path, host-pointer entries: a LANE = one stream + pinned, device-mapped host buffers.  The kernel reads the
+// parameters from them and writes loglik / info into them directly (zero-copy over PCIe: 8 (2L+1) bytes in, 12 bytes out per
+// evaluation), so a call is pack + ONE launch + one stream synchronisation, without a single hipMemcpy.  Lane 0 serves
+// gpcc_loglik_batch; a large per-delay fit (gpcc_grid_loglik) runs several lanes from as many host threads.
+#define GPCC_MAX_LANES 4
+struct SmallLane {
+    hipStream_t stream = nullptr;
+    double *par = nullptr, *ll = nullptr;
+    int *info = nullptr, *row = nullptr;
+    long cap = 0;
+    void release()
+    {
+        if (par) hipHostFree(par);
+        if (ll) hipHostFree(ll);
+        if (info) hipHostFree(info);
+        if (row) hipHostFree(row);
+        if (stream) hipStreamDestroy(stream);
+        par = ll = nullptr; info = row = nullptr; stream = nullptr; cap = 0;
+    }
+};
 
 struct gpcc_handle_s {
     int device = 0;
@@ -46,7 +69,7 @@ struct gpcc_handle_s {
     int fused_solve = 1;     // option "fused_solve": left-looking groups run gpcc_syrk_diag + gpcc_update_solve (2 launches per step)
     int small_n = 1;         // option "small_n": N <= GPCC_SMALL_MAXN runs gpcc_small_eval (one launch per batch, one wave per evaluation,
                              // the matrix in registers; always fp64) instead of the tile kernels
-    long small_count = 0;    // evaluations that took that path so far ("small_n_count")
+    std::atomic<long> small_count{0};   // evaluations that took that path so far ("small_n_count")
     int share_tiles = 0;     // tile rows wholly inside band 1
     bool share_now = false;  // decision for the batch being enqueued
     // workspace
@@ -67,16 +90,12 @@ struct gpcc_handle_s {
     double *d_par = nullptr, *d_out = nullptr, *d_ocond = nullptr;
     int *d_oinfo = nullptr;
     long par_cap = 0;
-    // small-N path, host-pointer API: pinned, device-mapped host buffers -- the kernel reads the parameters from them and
-    // writes loglik / info into them directly (zero-copy over PCIe: 8 (2L+1) bytes in, 12 bytes out per evaluation), so a
-    // call is pack + ONE launch + one stream synchronisation, without a single hipMemcpy
-    double *hp_par = nullptr, *hp_ll = nullptr;
-    int *hp_info = nullptr, *hp_row = nullptr;
-    long hp_cap = 0;
+    SmallLane lanes[GPCC_MAX_LANES];
     double *d_cand = nullptr;   // gpcc_grid_loglik: the candidate-delay table (G x L) on the device
     long cand_cap = 0;
     int fit_speculate = 1;      // option "fit_speculate": speculative optimiser rounds on the small-N path (gpcc_fit.h)
     int fit_device_unpack = 1;  // option "fit_device_unpack": the small-N kernel unpacks the optimiser's vectors itself
+    int fit_threads = 0;        // option "fit_threads": host threads (lanes) of a small-N fit; 0 = by problem count
     // fp32 mode: a-posteriori accuracy guard.  Every evaluation reports the sum and the maximum of
     // K_ii / d_i over its pivots; where the error model built on them exceeds the budget, the evaluation is repeated
     // on an internal fp64 handle (`fb`, created on first use) and its result replaces the fp32 one.
@@ -117,7 +136,11 @@ static int fail(gpcc_handle_t h, int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (h) h->err = buf;
+    if (h) {
+        static std::mutex mu;   // lanes of one handle may fail at the same time
+        std::lock_guard<std::mutex> lk(mu);
+        h->err = buf;
+    }
     g_err = buf;
     return code;
 }
@@ -300,10 +323,7 @@ extern "C" int gpcc_destroy(gpcc_handle_t h)
     free_workspace(h);
     hipFree(h->d_t); hipFree(h->d_sig2); hipFree(h->d_resid); hipFree(h->d_band); hipFree(h->d_yv);
     hipFree(h->d_par); hipFree(h->d_out); hipFree(h->d_oinfo);
-    if (h->hp_par) hipHostFree(h->hp_par);
-    if (h->hp_ll) hipHostFree(h->hp_ll);
-    if (h->hp_info) hipHostFree(h->hp_info);
-    if (h->hp_row) hipHostFree(h->hp_row);
+    for (auto &ln : h->lanes) ln.release();
     hipFree(h->d_cand);
     hipFree(h->d_ocond); hipFree(h->d_fb_idx); hipFree(h->d_fb_par); hipFree(h->d_fb_out); hipFree(h->d_fb_info);
     if (h->fb) gpcc_destroy(h->fb);
@@ -345,6 +365,9 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->fit_speculate = v != 0;
     } else if (!strcmp(key, "fit_device_unpack")) {
         h->fit_device_unpack = v != 0;
+    } else if (!strcmp(key, "fit_threads")) {
+        if (v < 0 || v > GPCC_MAX_LANES) return fail(h, GPCC_ERR_ARGUMENT, "fit_threads must be in [0,%d]", GPCC_MAX_LANES);
+        h->fit_threads = (int)v;
     } else if (!strcmp(key, "fp32_guard")) {
         h->fp32_guard = v != 0;
     } else if (!strcmp(key, "fp32_refine")) {
@@ -379,6 +402,7 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "small_n")) return h->small_n;
     if (!strcmp(key, "fit_speculate")) return h->fit_speculate;
     if (!strcmp(key, "fit_device_unpack")) return h->fit_device_unpack;
+    if (!strcmp(key, "fit_threads")) return h->fit_threads;
     if (!strcmp(key, "small_n_max")) return GPCC_SMALL_MAXN;
     if (!strcmp(key, "small_n_active")) return (h->small_n && h->N <= GPCC_SMALL_MAXN) ? 1 : 0;
     if (!strcmp(key, "small_n_count")) return h->small_count;
@@ -877,20 +901,25 @@ static int enqueue_host_batch(gpcc_handle_t h, int M, const double *delays, cons
     return rc;
 }
 
-static int ensure_pinned(gpcc_handle_t h, long M)
+static int ensure_lane(gpcc_handle_t h, int li, long M)
 {
-    if (M <= h->hp_cap) return 0;
-    if (h->hp_par) hipHostFree(h->hp_par);
-    if (h->hp_ll) hipHostFree(h->hp_ll);
-    if (h->hp_info) hipHostFree(h->hp_info);
-    if (h->hp_row) hipHostFree(h->hp_row);
-    h->hp_par = h->hp_ll = nullptr; h->hp_info = h->hp_row = nullptr; h->hp_cap = 0;
+    SmallLane &ln = h->lanes[li];
+    if (!ln.stream) {
+        if (li == 0) HIPCHK(h, hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+        else HIPCHK(h, hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+    }
+    if (M <= ln.cap) return 0;
+    if (ln.par) hipHostFree(ln.par);
+    if (ln.ll) hipHostFree(ln.ll);
+    if (ln.info) hipHostFree(ln.info);
+    if (ln.row) hipHostFree(ln.row);
+    ln.par = ln.ll = nullptr; ln.info = ln.row = nullptr; ln.cap = 0;
     const long cap = M < 1024 ? 1024 : M + M / 2;
-    HIPCHK(h, hipHostMalloc((void **)&h->hp_par, sizeof(double) * cap * (2 * h->L + 1), hipHostMallocDefault));
-    HIPCHK(h, hipHostMalloc((void **)&h->hp_ll, sizeof(double) * cap, hipHostMallocDefault));
-    HIPCHK(h, hipHostMalloc((void **)&h->hp_info, sizeof(int) * cap, hipHostMallocDefault));
-    HIPCHK(h, hipHostMalloc((void **)&h->hp_row, sizeof(int) * cap, hipHostMallocDefault));
-    h->hp_cap = cap;
+    HIPCHK(h, hipHostMalloc((void **)&ln.par, sizeof(double) * cap * (2 * h->L + 1), hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc((void **)&ln.ll, sizeof(double) * cap, hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc((void **)&ln.info, sizeof(int) * cap, hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc((void **)&ln.row, sizeof(int) * cap, hipHostMallocDefault));
+    ln.cap = cap;
     return 0;
 }
 
@@ -904,18 +933,19 @@ extern "C" int gpcc_loglik_batch(gpcc_handle_t h, int M, const double *delays, c
     if (h->is_multi()) return multi_loglik_batch(h, M, delays, alpha, rho, loglik, info);
     GPCC_ON_DEVICE(h, h->device);
     if (small_path(h)) {   // zero-copy: parameters read from, results written to pinned host memory by the kernel itself
-        int rc = ensure_pinned(h, M);
+        int rc = ensure_lane(h, 0, M);
         if (rc) return rc;
+        SmallLane &ln = h->lanes[0];
         const long ML = (long)M * h->L;
-        memcpy(h->hp_par, delays, sizeof(double) * ML);
-        memcpy(h->hp_par + ML, alpha, sizeof(double) * ML);
-        memcpy(h->hp_par + 2 * ML, rho, sizeof(double) * M);
+        memcpy(ln.par, delays, sizeof(double) * ML);
+        memcpy(ln.par + ML, alpha, sizeof(double) * ML);
+        memcpy(ln.par + 2 * ML, rho, sizeof(double) * M);
         if (h->precision == GPCC_PRECISION_FP32) h->cond_host.assign(2 * (size_t)M, 0.0);   // evaluated in fp64: nothing to guard
-        rc = enqueue_small(h, M, h->hp_par, h->hp_par + ML, h->hp_par + 2 * ML, h->hp_ll, h->hp_info, h->main_stream);
+        rc = enqueue_small(h, M, ln.par, ln.par + ML, ln.par + 2 * ML, ln.ll, ln.info, ln.stream);
         if (rc) return rc;
-        HIPCHK(h, hipStreamSynchronize(h->main_stream));
-        memcpy(loglik, h->hp_ll, sizeof(double) * M);
-        memcpy(info, h->hp_info, sizeof(int) * M);
+        HIPCHK(h, hipStreamSynchronize(ln.stream));
+        memcpy(loglik, ln.ll, sizeof(double) * M);
+        memcpy(info, ln.info, sizeof(int) * M);
         return 0;
     }
     int rc = enqueue_host_batch(h, M, delays, alpha, rho, nullptr, nullptr);
@@ -1330,23 +1360,25 @@ struct FitEval {
     std::vector<double> delays, alpha, rho, ll;
     std::vector<int> info;
     bool device_unpack = false;   // single-device small-N handle: the kernel unpacks the optimiser's vectors (fit_eval_small)
+    int lane = 0;                 // ... through this lane (stream + pinned buffers) of the handle
+    long p0 = 0;                  // global index of this optimiser's problem 0 (a fit may be cut into slices, one per lane)
 };
 
 // the small-N route of an optimiser round: X and the delay rows go to pinned memory as they are, the kernel unpacks
 static int fit_eval_small(gpcc_handle_t h, const FitEval &e, long K, const long *pidx, const double *X, double *f)
 {
     GPCC_ON_DEVICE(h, h->device);
-    int rc = ensure_pinned(h, K);
+    int rc = ensure_lane(h, e.lane, K);
     if (rc) return rc;
+    SmallLane &ln = h->lanes[e.lane];
     const int n = e.L + 1;
-    memcpy(h->hp_par, X, sizeof(double) * K * n);
-    for (long i = 0; i < K; ++i) h->hp_row[i] = (int)(pidx[i] / e.R);
-    rc = enqueue_small(h, (int)K, h->d_cand, nullptr, nullptr, h->hp_ll, h->hp_info, h->main_stream, h->hp_par, h->hp_row,
-                       e.rhomin, e.rhomax);
+    memcpy(ln.par, X, sizeof(double) * K * n);
+    for (long i = 0; i < K; ++i) ln.row[i] = (int)((e.p0 + pidx[i]) / e.R);
+    rc = enqueue_small(h, (int)K, h->d_cand, nullptr, nullptr, ln.ll, ln.info, ln.stream, ln.par, ln.row, e.rhomin, e.rhomax);
     if (rc) return rc;
-    HIPCHK(h, hipStreamSynchronize(h->main_stream));
+    HIPCHK(h, hipStreamSynchronize(ln.stream));
     for (long i = 0; i < K; ++i)   // safewrapper(negativeobjective), :149-153: a failed evaluation is +Inf
-        f[i] = h->hp_info[i] == 0 ? -h->hp_ll[i] : std::numeric_limits<double>::infinity();
+        f[i] = ln.info[i] == 0 ? -ln.ll[i] : std::numeric_limits<double>::infinity();
     return 0;
 }
 
@@ -1358,7 +1390,7 @@ int fit_eval(void *vctx, long K, const long *pidx, const double *X, double *f)
     if (e.device_unpack) return fit_eval_small(e.h, e, K, pidx, X, f);
     e.delays.resize(K * L); e.alpha.resize(K * L); e.rho.resize(K); e.ll.resize(K); e.info.resize(K);
     for (long i = 0; i < K; ++i)
-        for (int l = 0; l < L; ++l) e.delays[i * L + l] = e.cand[(pidx[i] / e.R) * L + l];
+        for (int l = 0; l < L; ++l) e.delays[i * L + l] = e.cand[((e.p0 + pidx[i]) / e.R) * L + l];
     int rc = gpcc_unpack_params((int)K, L, X, e.rhomin, e.rhomax, e.alpha.data(), e.rho.data());
     if (rc) return rc;
     rc = gpcc_loglik_batch(e.h, (int)K, e.delays.data(), e.alpha.data(), e.rho.data(), e.ll.data(), e.info.data());
@@ -1405,30 +1437,82 @@ extern "C" int gpcc_grid_loglik(gpcc_handle_t h, int G, const double *delays, in
         ev.device_unpack = true;
     }
 
-    // the best of the random candidates starts each problem (:209); problem p = (delay p / R, restart p % R) and
-    // every delay sees the same candidates (each reference gpcc call seeds its own generator with `seed`)
-    std::vector<long> pid((size_t)P * C);
-    std::vector<double> X((size_t)P * C * n), f0((size_t)P * C), x0((size_t)P * n);
-    for (long p = 0; p < P; ++p)
-        for (int c = 0; c < C; ++c) {
-            pid[p * C + c] = p;
-            memcpy(&X[(p * C + c) * n], &cands[((size_t)(p % R) * C + c) * n], sizeof(double) * n);
-        }
-    int rc = fit_eval(&ev, P * C, pid.data(), X.data(), f0.data());
-    if (rc) return rc;
-    for (long p = 0; p < P; ++p) {
-        int best = 0;
-        for (int c = 1; c < C; ++c)
-            if (f0[p * C + c] < f0[p * C + best]) best = c;
-        memcpy(&x0[p * n], &X[(p * C + best) * n], sizeof(double) * n);
-    }
-    gpccfit::BatchedNelderMead nm(P, n, iterations, 1e-6);            // Optim.Options(iterations, g_tol = 1e-6), :205
-    // small-N kernels: an evaluation's value does not depend on what else is in the batch, and up to ~4 waves per CU
-    // cost no more time than one -- so latency-bound rounds evaluate the whole decision tree of an iteration at once
-    if (small_fit && h->fit_speculate) nm.speculate_max = 1024;
+    // Problems p = (delay p / R, restart p % R), p in [lo, hi): the best of the random candidates starts each (:209; every
+    // delay sees the same candidates -- each reference gpcc call seeds its own generator with `seed`), then the lock-step
+    // Nelder-Mead.  A slice is self-contained: own optimiser, own evaluator state, own lane.
     std::vector<double> xmin((size_t)P * n), fmin(P);
-    rc = nm.run(fit_eval, &ev, x0.data(), xmin.data(), fmin.data());
-    if (rc) return rc;
+    std::vector<int> its(P);
+    auto fit_slice = [&](FitEval sev, long lo, long hi, long long *f_calls, long long *rounds) -> int {
+        const long Ps = hi - lo;
+        sev.p0 = lo;
+        std::vector<long> pid((size_t)Ps * C);
+        std::vector<double> X((size_t)Ps * C * n), f0((size_t)Ps * C), x0((size_t)Ps * n);
+        for (long p = 0; p < Ps; ++p)
+            for (int c = 0; c < C; ++c) {
+                pid[p * C + c] = p;
+                memcpy(&X[(p * C + c) * n], &cands[((size_t)((lo + p) % R) * C + c) * n], sizeof(double) * n);
+            }
+        int rc = fit_eval(&sev, Ps * C, pid.data(), X.data(), f0.data());
+        if (rc) return rc;
+        for (long p = 0; p < Ps; ++p) {
+            int best = 0;
+            for (int c = 1; c < C; ++c)
+                if (f0[p * C + c] < f0[p * C + best]) best = c;
+            memcpy(&x0[p * n], &X[(p * C + best) * n], sizeof(double) * n);
+        }
+        gpccfit::BatchedNelderMead nm(Ps, n, iterations, 1e-6);       // Optim.Options(iterations, g_tol = 1e-6), :205
+        // small-N kernels: an evaluation's value does not depend on what else is in the batch, and up to ~4 waves per CU
+        // cost no more time than one -- so latency-bound rounds evaluate the whole decision tree of an iteration at once
+        if (small_fit && h->fit_speculate) nm.speculate_max = 1024;
+        rc = nm.run(fit_eval, &sev, x0.data(), &xmin[(size_t)lo * n], &fmin[lo]);
+        if (rc) return rc;
+        for (long p = 0; p < Ps; ++p) its[lo + p] = nm.it[p];
+        *f_calls = nm.f_calls + Ps * C;
+        *rounds = nm.rounds + 1;
+        return 0;
+    };
+    // Large grids on the small-N path (README.md:227: 111 x 111 delay pairs): the host side of a round -- simplex arithmetic
+    // of thousands of problems, packing -- is as long as the kernel, so the problems are cut into slices that run on their
+    // own host threads, streams and pinned buffers: one slice's host work overlaps the others' kernels.  Every problem
+    // keeps its trajectory (its evaluations do not depend on the batch they travel in): same results as one slice.
+    int T = 1;
+    if (small_fit && ev.device_unpack && !h->prof) {
+        T = h->fit_threads > 0 ? h->fit_threads : (int)std::min<long>(GPCC_MAX_LANES, P / 2048);
+        if (T < 1) T = 1;
+        if (T > P) T = (int)P;
+    }
+    long long f_calls = 0, rounds = 0;
+    if (T == 1) {
+        const int rc = fit_slice(ev, 0, P, &f_calls, &rounds);
+        if (rc) return rc;
+    } else {
+        std::vector<int> rcs(T, 0);
+        std::vector<long long> fc(T, 0), rd(T, 0);
+        std::vector<std::thread> workers;
+        try {
+            for (int t = 0; t < T; ++t) {
+                FitEval sev = ev;
+                sev.lane = t;
+                const long lo = P * t / T, hi = P * (t + 1) / T;
+                workers.emplace_back([&, sev, lo, hi, t] { rcs[t] = fit_slice(sev, lo, hi, &fc[t], &rd[t]); });
+            }
+        } catch (...) {   // thread creation failed: run what is missing here (the library never throws across the C ABI)
+            for (auto &w : workers) w.join();
+            const int started = (int)workers.size();
+            workers.clear();
+            for (int t = started; t < T; ++t) {
+                FitEval sev = ev;
+                sev.lane = t;
+                rcs[t] = fit_slice(sev, P * t / T, P * (t + 1) / T, &fc[t], &rd[t]);
+            }
+        }
+        for (auto &w : workers) w.join();
+        for (int t = 0; t < T; ++t) {
+            if (rcs[t]) return rcs[t];
+            f_calls += fc[t];
+            rounds = std::max(rounds, rd[t]);   // slices advance side by side
+        }
+    }
     for (int g = 0; g < G; ++g) {
         long pick = (long)g * R;                                     // best restart, :224
         for (int r = 1; r < R; ++r)
@@ -1436,11 +1520,11 @@ extern "C" int gpcc_grid_loglik(gpcc_handle_t h, int G, const double *delays, in
         loglik_out[g] = -fmin[pick];                                 // :351
         gpcc_unpack_params(1, L, &xmin[pick * n], rhomin, rhomax, alpha_out + (long)g * L, rho_out + g);
         info_out[g] = std::isfinite(fmin[pick]) ? 0 : 1;             // 1: no candidate and no simplex vertex was valid
-        if (iterations_out) iterations_out[g] = nm.it[pick];
+        if (iterations_out) iterations_out[g] = its[pick];
     }
     if (stats_out) {
-        stats_out[0] = nm.f_calls + P * C;
-        stats_out[1] = nm.rounds + 1;
+        stats_out[0] = f_calls;
+        stats_out[1] = rounds;
     }
     return 0;
 }

@@ -249,3 +249,23 @@ def test_unpack_on_the_device_is_bitwise_the_hosts(gp):
             obj.set_option("fit_device_unpack", 1)
             assert all(np.array_equal(u, v) for u, v in zip(a[:5], b[:5])), i
     assert np.isfinite(ll[info == 0]).all()
+
+
+def test_fit_sliced_over_host_threads_changes_no_bit(gp):
+    """A large grid is cut into slices that run on their own host threads / streams / pinned buffers (lanes): same
+    results as one slice, for every thread count, with restarts straddling the cuts."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([40, 35, 30], seed=6, gap_band=1, span=20.0)
+    rng = np.random.default_rng(2)
+    G = 257
+    cand = np.concatenate([np.zeros((G, 1)), rng.uniform(0.0, 8.0, (G, 2))], axis=1)
+    with gp.Objective(t, y, s, "matern52") as obj:
+        obj.set_option("fit_threads", 1)
+        base = obj.grid_loglik(cand, 60, numberofrestarts=3, rhomax=100.0, seed=3)
+        for T in (2, 3, 4):
+            obj.set_option("fit_threads", T)
+            r = obj.grid_loglik(cand, 60, numberofrestarts=3, rhomax=100.0, seed=3)
+            assert all(np.array_equal(u, v) for u, v in zip(r[:5], base[:5])), T
+        with pytest.raises(gp.GpccError):
+            obj.set_option("fit_threads", 5)
+    assert (base[3] == 0).all()
