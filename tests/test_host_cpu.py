@@ -86,3 +86,19 @@ def test_native_optimiser_under_sanitizers(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout + run.stderr[-3000:]
     assert "rosenbrock" in run.stdout and "bowl5: ok" in run.stdout and "initial_params: ok" in run.stdout
+
+
+def test_julia_shim_file_matches_integration_md_and_the_header():
+    """julia/gpcchip.jl is the shim of INTEGRATION.md section 1 verbatim (never executed: no Julia here), and every C symbol
+    it ccalls is declared by include/gpcc_hip.h."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shim = open(os.path.join(root, "julia", "gpcchip.jl")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    body = shim[shim.index("# Thin ccall layer"):]
+    assert body in doc
+    header = open(os.path.join(root, "include", "gpcc_hip.h")).read()
+    syms = set(re.findall(r"ccall\(\(:(\w+), LIB\)", shim))
+    assert {"gpcc_create", "gpcc_destroy", "gpcc_loglik_batch", "gpcc_grid_loglik", "gpcc_probabilities", "gpcc_last_error"} <= syms
+    for sym in syms:
+        assert re.search(r"\b%s\(" % sym, header), sym

@@ -17,6 +17,8 @@
 #      their names (gpcc.jl_amd/csrc/gpcc_fit.h:24-31: softplus, logistic, eigenvalue lift); this prints what they really are
 #   5. one short gpcc(...; iterations = 20, seed = 1) run on the first 2-band case: minimum, α, ρ, postb -- the optimiser
 #      trajectory (Optim's Nelder-Mead, MersenneTwister draws) is unpinned in the build, so only the record is kept.
+#   6. Optim's NelderMead() on a deterministic objective from a fixed start, with the reference's options: per-iteration
+#      value / g_tol measure / step type / centroid ("optim_neldermead_trace") -- what pins gpcc_neldermead_batch.
 #
 # Usage (from an environment where `using GPCC` works, e.g. the package's own project with MiscUtil dev'ed in):
 #     julia --project=/path/to/GPCC.jl tools/pin_reference.jl [/path/to/this/repo]
@@ -29,6 +31,7 @@ catch
     Pkg.add("JSON")
     @eval using JSON
 end
+using Optim            # a dependency of GPCC.jl (Project.toml:12)
 using GPCC, MiscUtil, Distributions, LinearAlgebra, Statistics, Random, Printf
 
 root = length(ARGS) >= 1 ? ARGS[1] : normpath(joinpath(@__DIR__, ".."))
@@ -123,6 +126,32 @@ let c = first(filter(c -> length(c["t"]) == 2 && c["marginalise_b"] && c["kernel
     α, postb, ρ = length(rest) == 1 ? rest[1] : rest
     out["gpcc_iterations20_seed1"] = Dict("loglikel" => loglikel, "alpha" => α, "rho" => ρ, "postb_mean" => mean(postb),
                                           "postb_cov" => [cov(postb)[i, :] for i in 1:length(α)], "delays" => c["delays"])
+end
+
+# ---- 6. Optim's Nelder-Mead, iteration by iteration (pins gpcc_neldermead_batch / gpcc_fit.h / neldermead.py) ----------------
+# A deterministic objective with no randomness and no MiscUtil in it: the reference's own closure at FIXED delays on one
+# fixture, minimised from a FIXED start in (log alpha_1, log alpha_2, log rho) coordinates with exactly the options the
+# reference passes (marginaliseb.jl:205-211).  Recorded per iteration: f at the best vertex, the g_tol measure Optim tests,
+# the step type and the centroid (extended trace) -- enough to compare decision by decision with
+# tests/test_neldermead_cpu.py::reference_neldermead on the same objective.
+let c = first(filter(c -> length(c["t"]) == 2 && c["marginalise_b"] && c["kernel"] == "matern32", golden["cases"]))
+    t, y, sg, τ = vv(c["t"]), vv(c["y"]), vv(c["sigma"]), Float64.(c["delays"])
+    negobj(x) = try
+        -reference_objective(GPCC.matern32, t, y, sg, τ, exp.(x[1:2]), exp(x[3]), true)
+    catch e
+        isa(e, PosDefException) ? Inf : rethrow(e)
+    end
+    x0 = [log.(Float64.(c["alpha"])); log(Float64(c["rho"]))] .+ [0.3, -0.2, 0.5]
+    opt = Optim.Options(iterations = 60, show_trace = false, store_trace = true, extended_trace = true, g_tol = 1e-6)
+    res = Optim.optimize(negobj, x0, Optim.NelderMead(), opt)
+    tr = Optim.trace(res)
+    out["optim_neldermead_trace"] = Dict(
+        "x0" => x0, "objective" => "-objective(exp.(x[1:2]), exp(x[3])) of golden case (2 bands, marginalise_b, matern32), delays fixed",
+        "iterations" => Optim.iterations(res), "f_calls" => Optim.f_calls(res), "minimum" => Optim.minimum(res),
+        "minimizer" => Optim.minimizer(res), "converged" => Optim.converged(res),
+        "value" => [s.value for s in tr], "g_norm" => [s.g_norm for s in tr],
+        "step_type" => [get(s.metadata, "step_type", "") for s in tr],
+        "centroid" => [get(s.metadata, "centroid", Float64[]) for s in tr])
 end
 
 worst = maximum(vcat([d["rel"] for d in cases], [d["rel_Kxy"] for d in covs], [d["rel_Kxx"] for d in covs],

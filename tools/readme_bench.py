@@ -52,6 +52,37 @@ def cpu_port_rate(w, kernel, seconds):
     return n / (time.perf_counter() - t0), nthreads
 
 
+class OraclePort:
+    """Objective-shaped wrapper of the CPU port (oracle.loglik_batch): the SAME lock-step optimiser host logic
+    (gpcc_amd.fit / neldermead.py) then runs the README's fit on the host cores -- the CPU number beside the GPU's."""
+
+    def __init__(self, kernel, w, nthreads):
+        from oracle import oracle
+        oracle.build()
+        self.o, self.k, self.w, self.nthreads = oracle, kernel, w, nthreads
+
+    def loglik_batch(self, delays, alpha, rho):
+        return self.o.loglik_batch(self.k, self.w["t"], self.w["y"], self.w["s"], delays, alpha, rho, True, nthreads=self.nthreads)
+
+
+def cpu_port_fit(w, kernel, iterations, max_points):
+    """fitted grid points/s of the CPU port on a bounded sample of the sweep's delays (all of them when <= max_points)."""
+    from gpcc_amd import api, fit
+    cand = w["cand"]
+    if len(cand) > max_points:
+        cand = cand[np.linspace(0, len(cand) - 1, max_points).astype(int)]
+    nthreads = min(len(os.sched_getaffinity(0)), 16)
+    obj = OraclePort(kernel, w, nthreads)
+    t0 = time.perf_counter()
+    res = fit.gpcc_grid(w["t"], w["y"], w["s"], kernel=kernel, candidatedelays=cand, iterations=iterations, rhomax=300.0, seed=1,
+                        objective=obj, engine="python", unpack=api.unpack_params)
+    dt = time.perf_counter() - t0
+    return {"cpu_port_fit_points": len(cand), "cpu_port_fit_seconds": round(dt, 3), "cpu_port_fitted_grid_points_per_s": round(len(cand) / dt, 2),
+            "cpu_port_fit_evaluations": int(res.f_calls), "cpu_port_fit_rounds": int(res.rounds), "cpu_port_threads": nthreads,
+            "cpu_port_what": "oracle/ C restatement (scalar assembly + own Cholesky), %d threads over the evaluations of a round, "
+                             "numpy lock-step Nelder-Mead (gpcc_amd/neldermead.py); NOT the Julia reference (no Julia here)" % nthreads}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iterations", type=int, default=1000)
@@ -61,6 +92,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--option", action="append", default=[])
     ap.add_argument("--no-fit", action="store_true")
+    ap.add_argument("--cpu-fit-points", type=int, default=0, help="> 0: also run the fit on the CPU port, on at most this many delays of each sweep")
     args = ap.parse_args()
 
     import gpcc_amd
@@ -107,6 +139,10 @@ def main():
             out["cpu_port_threads"] = nthreads
             if "objective_evaluations" in out:
                 out["cpu_port_fit_seconds_estimate"] = round(out["objective_evaluations"] / rate, 1)
+        if args.cpu_fit_points > 0:
+            out.update(cpu_port_fit(w, args.kernel, args.iterations, args.cpu_fit_points))
+            if "fitted_grid_points_per_s" in out:
+                out["gpu_over_cpu_port_fit"] = round(out["fitted_grid_points_per_s"] / out["cpu_port_fitted_grid_points_per_s"], 1)
         print(json.dumps(out), flush=True)
 
 
