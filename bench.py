@@ -114,6 +114,7 @@ def native_multi(args, ndev):
             ll, info, p = step()
         elapsed = time.perf_counter() - t0
         mode = {1: "rccl", 2: "host"}.get(obj.get_option("gather_mode"), "?")
+        comp_ms, gather_ms, total_ms = obj.multi_stats()     # of the LAST step: where a scaling loss would come from
     print(json.dumps({
         "metric": "delay-grid loglik evals/sec (N=%d, %d-band %s)" % (L * Nb, L, {"matern32": "Matern-3/2", "matern52": "Matern-5/2"}.get(args.kernel, args.kernel)),
         "value": round(Gtot * args.steps / elapsed, 2), "unit": "evals/s", "n_gpus": N_, "steps": args.steps, "warmup": args.warmup,
@@ -122,6 +123,8 @@ def native_multi(args, ndev):
         "config": {"workload": "%d-band synthetic N=%d per band (N=%d), %s %s, %d-point delay grid per GPU" % (L, Nb, L * Nb, args.kernel, args.precision, G),
                    "grid_total": Gtot, "devices": devs,
                    "parallelism": "ONE process, multi-device handle x%d, 1 all-gather inside libgpcc_hip (%s)" % (N_, mode)},
+        "last_step": {"per_device_compute_ms": [round(float(x), 3) for x in comp_ms], "gather_ms": round(gather_ms, 3),
+                      "call_ms": round(total_ms, 3)},
         "info_nonzero": int((info != 0).sum()), "posterior_sum": float(p.sum()), "roofline": None, "cpu_baseline": None}))
 
 

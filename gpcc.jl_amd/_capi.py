@@ -29,6 +29,7 @@ SIGNATURES = {
     "gpcc_create_multi": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, c_int_p, c_double_p, c_double_p,
                                          c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_int_p, ctypes.c_int]),
     "gpcc_multi_gathered": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_long_p, c_double_p, ctypes.c_long]),
+    "gpcc_multi_stats": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, c_double_p]),
     "gpcc_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_long]),
     "gpcc_get_option": (ctypes.c_long, [ctypes.c_void_p, ctypes.c_char_p]),
     "gpcc_get_constants": (ctypes.c_int, [ctypes.c_void_p, c_double_p, c_double_p, c_double_p]),
@@ -117,6 +118,19 @@ def loaded_rocm_libraries():
     return seen
 
 
+def _assert_one_rocm_runtime():
+    """Two HIP (or HSA) runtimes in one process is the failure _share_torch_rocm_runtime exists to prevent -- e.g. a torch
+    wheel whose bundled libamdhip64 carries another SONAME than the `libamdhip64.so.7` libgpcc_hip.so was linked against.
+    The second runtime finds no GPU ("No HIP GPUs are available") far from its cause, so say it here."""
+    libs = loaded_rocm_libraries()
+    for stem in ("libamdhip64", "libhsa-runtime64"):
+        paths = sorted({os.path.realpath(p) for p in libs if os.path.basename(p).startswith(stem)})
+        if len(paths) > 1:
+            raise ImportError("two copies of %s are mapped into this process (%s): libgpcc_hip.so and another component "
+                              "(torch?) would each open the GPU through their own runtime.  Build libgpcc_hip.so against the "
+                              "ROCm libraries the other component ships, or import it in a process of its own." % (stem, ", ".join(paths)))
+
+
 def load():
     """Loads csrc/libgpcc_hip.so; raises if it has not been built (no fallback)."""
     global _lib
@@ -126,6 +140,7 @@ def load():
                               "(hipcc --offload-arch=gfx950).  gpcc_amd has no CPU fallback." % LIB_PATH)
         _share_torch_rocm_runtime()
         lib = ctypes.CDLL(LIB_PATH)
+        _assert_one_rocm_runtime()
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
             fn.restype = res

@@ -220,6 +220,14 @@ class Objective:
         buf = buf.reshape(n, 2, blk.value)
         return buf[:, 0, :], buf[:, 1, :].astype(np.int32)
 
+    def multi_stats(self):
+        """Multi-device handles: timing of the last loglik_batch -> (compute_ms per device, gather_ms, total_ms)."""
+        n = self.get_option("n_devices")
+        comp = np.empty(n, dtype=np.float64)
+        g, tot = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        self._chk(_capi.load().gpcc_multi_stats(self._h, _dp(comp), ctypes.byref(g), ctypes.byref(tot)))
+        return comp, g.value, tot.value
+
     # -- the hot path ---------------------------------------------------------------------------
     def _params(self, delays, alpha, rho):
         rho = _d(np.atleast_1d(rho))

@@ -1,11 +1,12 @@
 """Builds csrc/libgpcc_hip.so (hipcc, gfx950 only).  Cross-compiles without a GPU."""
 import os
+import shutil
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GPCC_HIP_LIB") or os.path.join(CSRC, "libgpcc_hip.so")
-_SOURCES = ["gpcc_hip.hip", "gpcc_kernels.hip.h", "gpcc_small.hip.h", "gpcc_fit.h"]
+_SOURCES = ["gpcc_hip.hip", "gpcc_kernels.hip.h", "gpcc_small.hip.h", "gpcc_fit.h", "gpcc_transforms.h"]
 _HEADER = os.path.join(os.path.dirname(_HERE), "include", "gpcc_hip.h")
 
 
@@ -25,8 +26,13 @@ def build(force=False, verbose=False):
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     tmp = "%s.tmp%d" % (LIB_PATH, os.getpid())      # link elsewhere, then rename: no reader ever sees a partial file
+    # librccl from the ROCm tree this hipcc belongs to (ROCM_PATH, else <hipcc>/../lib), not a hard-coded /opt/rocm
+    rocm = os.environ.get("ROCM_PATH") or os.path.dirname(os.path.dirname(os.path.realpath(shutil.which(hipcc) or hipcc)))
+    libdir = os.path.join(rocm, "lib")
+    if not os.path.isdir(libdir):
+        libdir = "/opt/rocm/lib"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           "-o", tmp, os.path.join(CSRC, "gpcc_hip.hip"), "-L/opt/rocm/lib", "-lrccl", "-pthread"]
+           "-o", tmp, os.path.join(CSRC, "gpcc_hip.hip"), "-L" + libdir, "-lrccl", "-pthread"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode:
         print(" ".join(cmd))

@@ -14,6 +14,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <limits>
 #include <mutex>
 #include <string>
@@ -45,6 +49,56 @@ struct SmallLane {
         if (row) hipHostFree(row);
         if (stream) hipStreamDestroy(stream);
         par = ll = nullptr; info = row = nullptr; stream = nullptr; cap = 0;
+    }
+};
+
+// one persistent host thread per device of a multi-device handle: it takes a job (this device's share of a batch), runs it
+// with its device current, and reports back -- no thread is created or joined per batch
+struct MultiWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, done = true, stop = false;
+    int rc = 0;
+    void loop()
+    {
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return has_job || stop; });
+            if (stop) return;
+            std::function<int()> f = std::move(job);
+            has_job = false;
+            lk.unlock();
+            const int r = f();
+            lk.lock();
+            rc = r;
+            done = true;
+            cv.notify_all();
+        }
+    }
+    void submit(std::function<int()> f)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        job = std::move(f);
+        has_job = true;
+        done = false;
+        cv.notify_all();
+    }
+    int wait()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done; });
+        return rc;
+    }
+    void shutdown()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+            cv.notify_all();
+        }
+        if (th.joinable()) th.join();
     }
 };
 
@@ -105,6 +159,7 @@ struct gpcc_handle_s {
     double *d_fb_par = nullptr, *d_fb_out = nullptr;
     gpcc_handle_t fb = nullptr;
     long fb_count = 0;               // evaluations repeated in fp64 so far ("fp32_guard_count")
+    long fb_slots = 0;               // slots of the fp64 workspace behind the guard
     std::vector<double> cond_host, ll_host, sigma_host;
     std::vector<int> info_host, fb_idx_host;
     // profiling
@@ -120,6 +175,11 @@ struct gpcc_handle_s {
     std::vector<ncclComm_t> comms;        // one per sub-handle when the gather is RCCL's
     std::vector<double *> d_send, d_recv; // per sub: [loglik(blk) | info(blk)] and n x that
     std::vector<double> h_gather;
+    std::vector<std::unique_ptr<MultiWorker>> workers;   // one per sub-handle, started on the first batch
+    bool workers_failed = false;          // thread creation failed once: shares run one after the other on the calling thread
+    std::vector<hipEvent_t> ev_a, ev_b;   // per sub: around its share of the last batch (statistics)
+    std::vector<double> stat_compute_ms;  // per device: its share of the last batch, on its stream (HIP events)
+    double stat_gather_ms = 0.0, stat_total_ms = 0.0;   // the all-gather + final copies, and the whole call, host wall clock
     long gather_cap = 0;                  // evaluations per device the gather buffers hold
     long gather_blk = 0;                  // block length of the last gathered batch
     int gather_mode = 0;                  // GPCC_GATHER_*
@@ -808,9 +868,24 @@ static int fp32_guard_pass(gpcc_handle_t h, int M, const double *d_delays, const
         int rc = gpcc_create(&h->fb, h->L, h->Nl, h->t_host.data(), h->y_host.data(), h->sigma_host.data(), h->kernel_id, h->mb,
                              GPCC_PRECISION_FP64, h->device);
         if (rc) return fail(h, rc, "fp32 guard: creating the fp64 handle failed: %s", g_err.c_str());
-        const long per = gpcc_get_option(h->fb, "slots_per_stream");
-        gpcc_set_option(h->fb, "slots_per_stream", per < 16 ? per : 16);
         gpcc_set_option(h->fb, "shared_prefix", 0);
+        h->fb_slots = 0;
+    }
+    {   // workspace of the fp64 repeat: as many slots as evaluations to repeat (a batch that is mostly ill-conditioned then
+        // runs as few large groups on the fused path instead of many 16-wide right-looking ones), between 16 and 128,
+        // within a quarter of the memory that is free right now; it only ever grows
+        size_t free_b = 0, total_b = 0;
+        long want = nf < 16 ? 16 : (nf > 128 ? 128 : nf);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const long per_slot = gpcc_get_option(h->fb, "bytes_per_slot");
+            const long fit = per_slot > 0 ? (long)(free_b / 4 / (size_t)per_slot) : want;
+            if (want > fit) want = fit;
+        }
+        if (want < 1) want = 1;
+        if (want > h->fb_slots) {
+            gpcc_set_option(h->fb, "slots_per_stream", want);
+            h->fb_slots = want;
+        }
     }
     if (nf > h->fb_cap) {
         hipFree(h->d_fb_idx); hipFree(h->d_fb_par); hipFree(h->d_fb_out); hipFree(h->d_fb_info);
@@ -1044,14 +1119,18 @@ static int run_augmented(gpcc_handle_t h, const double *delays, const double *al
 static int fetch_augmented(gpcc_handle_t h, AugRun &a, double *block, double *zext, double *loglik, int *info, double jitter,
                            int symmetric = 1)
 {
+    // (run_augmented restored the caller's current device on return: allocate and launch on the handle's again)
+    DeviceGuard guard_(h, h->device);
+    if (guard_.rc) { a.release(); return guard_.rc; }
     hipStream_t s = h->main_stream;
     const long nn = (long)a.next * a.next;
     double *d_dense = nullptr;
     hipError_t e = hipMalloc(&d_dense, sizeof(double) * nn);
     if (e == hipSuccess) {
         gpcc_export_dense<double><<<(unsigned)((nn + 255) / 256), 256, 0, s>>>(a.c, 0, d_dense, symmetric, a.off, a.next, jitter);
-        e = hipMemcpyAsync(block, d_dense, sizeof(double) * nn, hipMemcpyDeviceToHost, s);
+        e = hipGetLastError();
     }
+    if (e == hipSuccess) e = hipMemcpyAsync(block, d_dense, sizeof(double) * nn, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess && zext) e = hipMemcpyAsync(zext, a.c.z + a.off, sizeof(double) * a.next, hipMemcpyDeviceToHost, s);
     double ll = 0.0;
     int inf = 0;
@@ -1581,6 +1660,13 @@ static int multi_ensure_buffers(gpcc_handle_t h, long blk)
 
 static int multi_destroy(gpcc_handle_t h)
 {
+    for (auto &w : h->workers) w->shutdown();
+    h->workers.clear();
+    for (size_t i = 0; i < h->ev_a.size(); ++i) {
+        DeviceGuard g(nullptr, h->subs[i]->device);
+        hipEventDestroy(h->ev_a[i]);
+        hipEventDestroy(h->ev_b[i]);
+    }
     for (size_t i = 0; i < h->comms.size(); ++i) {
         DeviceGuard g(nullptr, h->subs[i]->device);
         ncclCommDestroy(h->comms[i]);
@@ -1640,6 +1726,7 @@ static int multi_worker(gpcc_handle_t h, int i, long blk, long lo, int cnt, cons
     GPCC_ON_DEVICE(sub, sub->device);
     int rc = ensure_staging(sub, cnt > 0 ? cnt : 1);
     if (rc) return rc;
+    HIPCHK(sub, hipEventRecord(h->ev_a[i], sub->main_stream));
     if (cnt > 0) {
         rc = enqueue_host_batch(sub, cnt, delays + lo * sub->L, alpha + lo * sub->L, rho + lo, h->d_send[i], sub->d_oinfo);
         if (rc) return rc;
@@ -1647,6 +1734,7 @@ static int multi_worker(gpcc_handle_t h, int i, long blk, long lo, int cnt, cons
     gpcc_pack_gather<<<(unsigned)((blk + 255) / 256), 256, 0, sub->main_stream>>>(cnt, blk, sub->d_oinfo, h->d_send[i]);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(sub, GPCC_ERR_HIP, "gpcc_pack_gather: %s", hipGetErrorString(e));
+    HIPCHK(sub, hipEventRecord(h->ev_b[i], sub->main_stream));
     if (h->gather_mode == GPCC_GATHER_HOST) {   // this device's block -> its place in the host gather buffer
         HIPCHK(sub, hipMemcpyAsync(h->h_gather.data() + (size_t)i * 2 * blk, h->d_send[i], sizeof(double) * 2 * blk,
                                    hipMemcpyDeviceToHost, sub->main_stream));
@@ -1662,18 +1750,50 @@ static int multi_loglik_batch(gpcc_handle_t h, int M, const double *delays, cons
     const long blk = ((long)M + n - 1) / n;
     int rc = multi_ensure_buffers(h, blk);
     if (rc) return rc;
-    std::vector<int> rcs(n, 0);
-    {
-        std::vector<std::thread> workers;
+    const auto t_begin = std::chrono::steady_clock::now();
+    if (h->ev_a.empty()) {
+        h->ev_a.assign(n, nullptr);
+        h->ev_b.assign(n, nullptr);
+        h->stat_compute_ms.assign(n, 0.0);
         for (int i = 0; i < n; ++i) {
-            const long lo = (long)i * blk;
-            const int cnt = (int)std::max(0L, std::min(blk, (long)M - lo));
-            workers.emplace_back([=, &rcs] { rcs[i] = multi_worker(h, i, blk, lo, cnt, delays, alpha, rho); });
+            GPCC_ON_DEVICE(h, h->subs[i]->device);
+            HIPCHK(h, hipEventCreate(&h->ev_a[i]));
+            HIPCHK(h, hipEventCreate(&h->ev_b[i]));
         }
-        for (auto &w : workers) w.join();
     }
+    if (h->workers.empty() && !h->workers_failed && n > 1) {
+        try {
+            for (int i = 0; i < n; ++i) {
+                h->workers.emplace_back(new MultiWorker());
+                MultiWorker *w = h->workers.back().get();
+                w->th = std::thread([w] { w->loop(); });
+            }
+        } catch (...) {   // no threads to be had: fall back to the calling thread (the library never throws across the C ABI)
+            for (auto &w : h->workers) w->shutdown();
+            h->workers.clear();
+            h->workers_failed = true;
+        }
+    }
+    std::vector<int> rcs(n, 0);
+    for (int i = 0; i < n; ++i) {
+        const long lo = (long)i * blk;
+        const int cnt = (int)std::max(0L, std::min(blk, (long)M - lo));
+        if (!h->workers.empty()) h->workers[i]->submit([=] { return multi_worker(h, i, blk, lo, cnt, delays, alpha, rho); });
+        else rcs[i] = multi_worker(h, i, blk, lo, cnt, delays, alpha, rho);
+    }
+    if (!h->workers.empty())
+        for (int i = 0; i < n; ++i) rcs[i] = h->workers[i]->wait();
     for (int i = 0; i < n; ++i)
-        if (rcs[i]) return multi_fail(h, h->subs[i], rcs[i]);
+        if (rcs[i]) {
+            // a share failed: the other devices' streams still hold enqueued work that reads the caller's buffers and the
+            // handle's staging -- drain them all before handing control back
+            for (int j = 0; j < n; ++j) {
+                DeviceGuard g(nullptr, h->subs[j]->device);
+                hipStreamSynchronize(h->subs[j]->main_stream);
+            }
+            return multi_fail(h, h->subs[i], rcs[i]);
+        }
+    const auto t_gather = std::chrono::steady_clock::now();
     h->gather_blk = blk;
     const size_t nb = sizeof(double) * 2 * blk;
     if (h->gather_mode == GPCC_GATHER_RCCL) {
@@ -1710,6 +1830,28 @@ static int multi_loglik_batch(gpcc_handle_t h, int M, const double *delays, cons
             info[lo + j] = (int)src[blk + j];
         }
     }
+    const auto t_end = std::chrono::steady_clock::now();
+    for (int i = 0; i < n; ++i) {   // every stream has drained: the events are complete
+        float ms = 0.f;
+        GPCC_ON_DEVICE(h, h->subs[i]->device);
+        h->stat_compute_ms[i] = hipEventElapsedTime(&ms, h->ev_a[i], h->ev_b[i]) == hipSuccess ? ms : -1.0;
+    }
+    h->stat_gather_ms = std::chrono::duration<double, std::milli>(t_end - t_gather).count();
+    h->stat_total_ms = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
+    return 0;
+}
+
+// per-device time of the last gpcc_loglik_batch on a multi-device handle (HIP events on each device's stream around its
+// share), the time of the gather phase (all-gather + final copies; in the host-gather mode the device-to-host copies run
+// inside the shares) and of the whole call (host wall clock): one run of a multi-GPU benchmark then shows WHERE a scaling
+// loss comes from -- an uneven share, a slow device, or the collective
+extern "C" int gpcc_multi_stats(gpcc_handle_t h, double *compute_ms, double *gather_ms, double *total_ms)
+{
+    if (!h || !h->is_multi()) return fail(h, GPCC_ERR_ARGUMENT, "not a multi-device handle");
+    if (h->stat_compute_ms.empty()) return fail(h, GPCC_ERR_STATE, "no batch has run on this handle yet");
+    if (compute_ms) memcpy(compute_ms, h->stat_compute_ms.data(), sizeof(double) * h->stat_compute_ms.size());
+    if (gather_ms) *gather_ms = h->stat_gather_ms;
+    if (total_ms) *total_ms = h->stat_total_ms;
     return 0;
 }
 

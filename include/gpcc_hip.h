@@ -78,6 +78,11 @@ int gpcc_create_multi(gpcc_handle_t *handle, int L, const int *Nl, const double 
  * (out == NULL only queries blk). */
 int gpcc_multi_gathered(gpcc_handle_t handle, int which, long *blk_out, double *out, long capacity);
 
+/* Timing of the last gpcc_loglik_batch on a multi-device handle: compute_ms[n_devices] = each device's share on its own
+ * stream (HIP events), *gather_ms = the gather phase (RCCL all-gather + final copy; host wall clock), *total_ms = the whole
+ * call.  Any pointer may be NULL.  (One persistent host thread per device runs the shares; none is created per batch.) */
+int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms, double *total_ms);
+
 /* Tunables: "streams" (groups in flight on separate HIP streams, default 1), "slots_per_stream"
  * (evaluations resident per group, default 256 = one diagonal-block workgroup per CU, capped so
  * the workspace stays under 64 GiB), "right_looking_max" (groups of at most this many evaluations use

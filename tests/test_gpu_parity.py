@@ -986,6 +986,8 @@ def test_multi_device_handle_matches_single_device(gp, oracle):
                 assert gl.shape == (len(devs), blk)
                 assert np.array_equal(gl.ravel()[:M], ref, equal_nan=True) and np.array_equal(gi.ravel()[:M], rinfo)
                 assert np.isnan(gl.ravel()[M:]).all()
+            comp_ms, gather_ms, total_ms = multi.multi_stats()    # of that batch: per-device share, gather phase, whole call
+            assert comp_ms.shape == (len(devs),) and np.all(comp_ms > 0) and gather_ms >= 0 and total_ms >= comp_ms.max() * 0.5
             few, finfo = multi.loglik_batch(delays[:2], alphas[:2], rhos[:2])       # fewer evaluations than devices
             assert np.array_equal(few, ref[:2]) and (finfo == 0).all()
             one = multi([alpha[0], alpha[1]], rho, delays[3])                        # objective(alpha, rho): M = 1
@@ -997,6 +999,85 @@ def test_multi_device_handle_matches_single_device(gp, oracle):
             assert np.all(np.isfinite(mu)) and Sig.shape == (3, 3)
     with pytest.raises(gp.GpccError):
         gp.Objective(t, y, s, gp.matern32, devices=[0, 99])
+
+
+def test_two_processes_share_one_gpu(gp, oracle, tmp_path, kernel_family):
+    """the reference parallelises with pmap WORKER PROCESSES, so the library must be safe for several processes
+    sharing one GPU (no process-global state beyond the handle).  Two fresh child processes, each with its own handle on
+    device 0, evaluate at the same time (file barrier) on the small-N path and on the tile path; both are checked against
+    the oracle."""
+    import os
+    import subprocess
+    import sys
+    from gpcc_amd import synthetic
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, GPCC_SMALL_N="0" if kernel_family == "tile" else "1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "_shared_gpu_worker.py"), str(r), str(tmp_path)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in (0, 1)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    for rank in (0, 1):
+        res = np.load(os.path.join(tmp_path, "result_%d.npz" % rank))
+        for tag, Nl in (("small", [60, 50]), ("tiles", [330, 310])):
+            t, y, s, _ = synthetic.simulate_lightcurves(Nl, seed=11 + rank, span=20.0)
+            alpha, rho = synthetic.default_hyperparameters(y)
+            d = res[tag + "_delays"]
+            ref, rinfo = oracle.loglik_batch("matern32", t, y, s, d, np.tile(alpha, (len(d), 1)), np.full(len(d), rho), True, nthreads=8)
+            assert (rinfo == 0).all() and _rel(res[tag], ref) <= LL_RTOL, (rank, tag)
+
+
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+def test_multi_gpu_rccl_gather_and_foreign_current_device(gp, oracle):
+    """Needs >= 2 GPUs (skipped on the one-GPU box): distinct devices take the RCCL route (ncclCommInitAll + grouped
+    ncclAllGather); every device must hold the whole rank-major vector; results equal the single-device handle's; and the
+    single-matrix utilities work from a thread whose current device is NOT the handle's (the DeviceGuard of every entry)."""
+    import threading
+    import torch
+    ndev = _gpu_count()
+    if ndev < 2:
+        pytest.skip("needs at least 2 GPUs")
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([300, 280], seed=8)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    M = 101
+    delays = np.stack([np.zeros(M), np.linspace(0.0, 10.0, M)], 1)
+    alphas, rhos = np.tile(alpha, (M, 1)), np.full(M, rho)
+    with gp.Objective(t, y, s, gp.matern32) as single:
+        single.set_option("right_looking_max", 0)
+        single.set_option("shared_prefix", 0)
+        ref, rinfo = single.loglik_batch(delays, alphas, rhos)
+        K_ref = single.model_matrix(delays[3], alpha, rho)
+    devs = list(range(min(ndev, 4)))
+    with gp.Objective(t, y, s, gp.matern32, devices=devs) as multi:
+        assert multi.get_option("gather_mode") == 1          # GPCC_GATHER_RCCL
+        multi.set_option("right_looking_max", 0)
+        multi.set_option("shared_prefix", 0)
+        ll, info = multi.loglik_batch(delays, alphas, rhos)
+        assert np.array_equal(ll, ref) and np.array_equal(info, rinfo)
+        for which in range(len(devs)):
+            gl, gi = multi.gathered(which)
+            assert np.array_equal(gl.ravel()[:M], ref) and np.array_equal(gi.ravel()[:M], rinfo)
+        comp_ms, gather_ms, total_ms = multi.multi_stats()
+        assert np.all(comp_ms > 0)
+    # a handle on the LAST device, driven from a thread whose current device is 0
+    out = {}
+    with gp.Objective(t, y, s, gp.matern32, device=ndev - 1) as far:
+        def work():
+            torch.cuda.set_device(0)
+            out["K"] = far.model_matrix(delays[3], alpha, rho)
+            out["mu"], out["Sig"] = far.predict(delays[3], alpha, rho, [np.array([1.0, 2.0]), np.array([3.0])])
+            out["postb"] = far.posterior_offsets(delays[3], alpha, rho)
+            out["dev"] = torch.cuda.current_device()
+        th = threading.Thread(target=work)
+        th.start()
+        th.join()
+    assert out["dev"] == 0                                   # the caller's current device is restored
+    np.testing.assert_allclose(out["K"], K_ref, rtol=1e-13)
+    assert np.all(np.isfinite(out["mu"])) and out["Sig"].shape == (3, 3) and np.all(np.isfinite(out["postb"][0]))
 
 
 def test_multi_device_rccl_route_with_one_rank(gp, monkeypatch):
