@@ -126,9 +126,15 @@ def _assert_one_rocm_runtime():
     for stem in ("libamdhip64", "libhsa-runtime64"):
         paths = sorted({os.path.realpath(p) for p in libs if os.path.basename(p).startswith(stem)})
         if len(paths) > 1:
-            raise ImportError("two copies of %s are mapped into this process (%s): libgpcc_hip.so and another component "
-                              "(torch?) would each open the GPU through their own runtime.  Build libgpcc_hip.so against the "
-                              "ROCm libraries the other component ships, or import it in a process of its own." % (stem, ", ".join(paths)))
+            msg = ("two copies of %s are mapped into this process (%s): libgpcc_hip.so and another component (torch?) may "
+                   "each open the GPU through their own runtime.  Build libgpcc_hip.so against the ROCm libraries the other "
+                   "component ships, or import it in a process of its own." % (stem, ", ".join(paths)))
+            if stem == "libamdhip64":
+                raise ImportError(msg)
+            # a second HSA runtime that is only mapped (rocprofv3 preloads the system copy for its tool library while the
+            # HIP runtime in use is torch's) does no harm: say so once, do not refuse
+            import warnings
+            warnings.warn(msg, RuntimeWarning, stacklevel=3)
 
 
 def load():

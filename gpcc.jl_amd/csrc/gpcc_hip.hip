@@ -121,6 +121,11 @@ struct gpcc_handle_s {
     int fused_solve_min = 112;   // ... from this group size on (below it the diagonal tile's serial K-loop on ONE CU per evaluation costs
                                  // more than the fused solve saves: measured crossover 96-128 evaluations at N = 1024 and N = 4096)
     int fused_solve = 1;     // option "fused_solve": left-looking groups run gpcc_syrk_diag + gpcc_update_solve (2 launches per step)
+    int hybrid_tail = 1;     // option "hybrid_tail": left-looking groups of the three-kernel path finish RIGHT-looking once their
+                             // trailing matrices fit the Infinity Cache and the left-looking steps would leave CUs idle
+    int hybrid_mall_mb = 400;   // option "hybrid_mall_mb": budget for the trailing matrices of a group (256 MiB Infinity Cache; measured
+                                // best at 400: profiles/r03/midsize_tail_budget_sweep.log)
+    int hybrid_occ = 384;       // option "hybrid_occ": ... and only steps with fewer left-looking jobs than this become right-looking
     int small_n = 1;         // option "small_n": N <= GPCC_SMALL_MAXN runs gpcc_small_eval (one launch per batch, one wave per evaluation,
                              // the matrix in registers; always fp64) instead of the tile kernels
     std::atomic<long> small_count{0};   // evaluations that took that path so far ("small_n_count")
@@ -421,6 +426,13 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->fused_solve_min = (int)v;
     } else if (!strcmp(key, "small_n")) {
         h->small_n = v != 0;
+    } else if (!strcmp(key, "hybrid_tail")) {
+        h->hybrid_tail = v != 0;
+    } else if (!strcmp(key, "hybrid_occ")) {
+        h->hybrid_occ = (int)v;
+    } else if (!strcmp(key, "hybrid_mall_mb")) {
+        if (v < 0 || v > 4096) return fail(h, GPCC_ERR_ARGUMENT, "hybrid_mall_mb must be in [0,4096]");
+        h->hybrid_mall_mb = (int)v;
     } else if (!strcmp(key, "fit_speculate")) {
         h->fit_speculate = v != 0;
     } else if (!strcmp(key, "fit_device_unpack")) {
@@ -460,6 +472,8 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "fused_solve")) return h->fused_solve;
     if (!strcmp(key, "fused_solve_min")) return h->fused_solve_min;
     if (!strcmp(key, "small_n")) return h->small_n;
+    if (!strcmp(key, "hybrid_tail")) return h->hybrid_tail;
+    if (!strcmp(key, "hybrid_mall_mb")) return h->hybrid_mall_mb;
     if (!strcmp(key, "fit_speculate")) return h->fit_speculate;
     if (!strcmp(key, "fit_device_unpack")) return h->fit_device_unpack;
     if (!strcmp(key, "fit_threads")) return h->fit_threads;
@@ -667,12 +681,36 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
         }
         return;
     }
+    // Hybrid tail (plain left-looking groups of a few dozen evaluations): a left-looking step is cnt (nt - k) jobs of k tile
+    // products, so the LAST steps are a few long jobs on a mostly idle chip (32 evaluations at N = 4096: steps 25-31 run at
+    // 75 ... 12 % of the 256 CUs, profiles/r03/midsize_update_per_step_plain_vs_splitk.log).  From step ks on the group therefore
+    // runs right-looking: ONE catch-up launch gives every trailing tile (I,J), I >= J >= ks, its whole sum over the finished
+    // columns < ks (cnt n(n+1)/2 equal jobs that stream the rows in lock-step through L2), then each step updates the trailing
+    // matrix with its one new column -- many short jobs, affordable because ks is chosen so that the trailing matrices of the
+    // whole group stay in the Infinity Cache.  Measured and dropped for the same purpose: split-K and stream-K decompositions
+    // of the update with a last-arriver reduction (bitwise deterministic; no gain: DESIGN.md 4.2d).
+    int ks = right ? 0 : c.nt_fact;   // first right-looking step
+    if (!right && !p && !g.spread && h->hybrid_tail && c.nt_fact == c.nt && c.nt >= 6) {
+        const double tile_mb = GPCC_TILE_ELEMS * sizeof(T) / 1048576.0;
+        int n = 0;
+        while ((double)g.cnt * (n + 1) * (n + 2) / 2 * tile_mb <= h->hybrid_mall_mb) ++n;   // trailing size the cache holds
+        const int nocc = (h->hybrid_occ + g.cnt - 1) / g.cnt;                                // steps with fewer left-looking jobs than that
+        if (n > nocc) n = nocc;
+        if (n > c.nt - 1) n = c.nt - 1;                                                      // (right-looking from step 1 on)
+        if (n >= 2) ks = c.nt - n;
+    }
     for (int k = 0; k < c.nt_fact; ++k) {
-        if (k > 0 && !right) {
+        const bool rstep = k >= ks;
+        if (k > 0 && !rstep) {
             ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
             const int grid = (k < p) ? cnt8 * (c.nt - p) + (p - k) : cnt8 * (c.nt - k);
             if (h->update_t && !p && c.nt_fact == c.nt) gpcc_update_solve<T, false><<<grid, GPCC_GEMM_THREADS, GPCC_UPSOLVE_LDS_BYTES, s>>>(c, g, k);
-            else gpcc_panel_update<T, false><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, k);
+            else gpcc_panel_update<T, false><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, k, 0);
+        }
+        if (k > 0 && k == ks) {   // catch-up: all trailing tiles (I,J), I >= J >= ks, minus their sums over columns 0 .. ks-1
+            ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
+            const int n = c.nt - k;
+            gpcc_panel_update<T, true><<<cnt8 * (n * (n + 1) / 2), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k - 1, k, 0);
         }
         {
             ProfScope pr(h, GPCC_PROF_DIAG, s);
@@ -683,16 +721,16 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
             const int grid = (k < p) ? cnt8 * (c.nt - p) + (p - k - 1) : cnt8 * (c.nt - k - 1);
             if (grid > 0) gpcc_panel_trsm<T><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
         }
-        if (right && k < c.nt - 1) {
+        if (rstep && k < c.nt - 1) {
             ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
             const int n = c.nt - k - 1;
-            gpcc_panel_update<T, true><<<cnt8 * (n * (n + 1) / 2), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, 1);
+            gpcc_panel_update<T, true><<<cnt8 * (n * (n + 1) / 2), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, 1, k);
         }
     }
     // augmented systems: Schur complement of the rows beyond the factorised columns,
     // S = C - V^T V with V = L^-1 [cross block]  
     for (int k = c.nt_fact; k < c.nt; ++k)
-        gpcc_panel_update<T, false><<<cnt8 * (c.nt - k), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, c.nt_fact);
+        gpcc_panel_update<T, false><<<cnt8 * (c.nt - k), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, c.nt_fact, 0);
 }
 
 // left-looking blocked Cholesky + fused forward solve (+ Schur complement of non-factorised rows)

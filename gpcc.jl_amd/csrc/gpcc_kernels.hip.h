@@ -27,7 +27,7 @@ static_assert(GPCC_DIAG_LDS_BYTES <= 160 * 1024, "gpcc_diag_factor's LDS image m
 #define GPCC_GEMM_LDS_BYTES (2 * 2 * GPCC_CHUNK_BYTES)
 #define GPCC_TRSM_ROWS_LDS_BYTES (4 * (GPCC_CHUNK_BYTES / 4 + GPCC_CHUNK_BYTES))   /* four stages of 4 KiB + 16 KiB */
 #define GPCC_GEMM_THREADS 512
-#define GPCC_RIGHT_LOOKING_MAX 24
+#define GPCC_RIGHT_LOOKING_MAX 12   /* larger groups: left-looking with a right-looking tail (gpcc_hip.hip: hybrid tail) */
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -377,8 +377,11 @@ __device__ __forceinline__ void gpcc_dma_chunk(const T *gA, const T *gB, T *stag
 // T(I,J) -= L(I,k) L(J,k)^T -- n(n+1)/2 short jobs (one tile of K) per evaluation instead of n long ones, so a
 // handful of matrices still fills the chip; it re-reads and re-writes the trailing matrix every step, which the
 // 256 MiB Infinity Cache absorbs for a few matrices but HBM would not for 256.
+// kcol = first tile column of the K loop: 0 for the left-looking form, k for a right-looking step.  RIGHT with kcol = 0 and
+// ktiles = k + 1 is the CATCH-UP of a group that switches from left- to right-looking at step k + 1: every trailing tile
+// (I,J), I >= J > k, receives the whole sum over the finished columns 0..k at once.
 template <typename T, bool RIGHT>
-__global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup g, int k, int ktiles)
+__global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup g, int k, int ktiles, int kcol)
 {
     typedef GpccPrec<T> P;
     constexpr int CH = GPCC_CHUNK_BYTES / sizeof(T);
@@ -421,8 +424,8 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
 
     T *tiles = (T *)c.tiles + (long)slot * c.slot_stride;
     const T *btiles = shared ? (const T *)c.tiles + (long)g.slot0 * c.slot_stride : tiles;
-    const T *gA = tiles + gpcc_tile_off(I, RIGHT ? k : 0);
-    const T *gB = btiles + gpcc_tile_off(J, RIGHT ? k : 0);
+    const T *gA = tiles + gpcc_tile_off(I, kcol);
+    const T *gB = btiles + gpcc_tile_off(J, kcol);
     T *Tt = tiles + gpcc_tile_off(I, J);
     const int nch = P::NCH * ktiles;  // ktiles = k (left-looking), 1 (right-looking), or nt_fact (Schur complement)
 

@@ -677,6 +677,7 @@ def test_shared_prefix_is_bitwise_identical(gp, Nl, prec):
     with gp.Objective(t, y, s, gp.matern32, precision=prec, slots_per_stream=40) as obj:
         assert obj.get_option("share_tiles") == Nl[0] // 128
         obj.set_option("shared_prefix", 0)
+        obj.set_option("hybrid_tail", 0)           # (the right-looking tail sums in another order; the bitwise comparison is between plain left-looking runs)
         dflt, dinfo = obj.loglik_batch(delays, alphas, rhos)     # default plain path: panel solve fused into the update
         obj.set_option("fused_solve", 0)           # the three-kernel path, whose kernels the shared-prefix mode runs
         ref, rinfo = obj.loglik_batch(delays, alphas, rhos)
@@ -931,6 +932,39 @@ def test_fused_solve_path_agrees_with_three_kernel_path(gp, oracle, Nl, prec, to
         assert _rel(a[ok], ref[ok]) <= (LL_RTOL if prec == "fp64" else FP32_RTOL)
 
 
+@pytest.mark.parametrize("Nl,prec,M,tol", [([700, 650], "fp64", 20, 1e-11), ([1024, 1024], "fp64", 40, 1e-11), ([520, 500, 490], "fp64", 13, 1e-11),
+                                            ([900, 800], "fp32", 30, 1e-5)])
+def test_right_looking_tail_agrees_with_plain_left_looking(gp, oracle, Nl, prec, M, tol):
+    """Groups of 13-111 evaluations run left-looking and finish right-looking (one catch-up launch, then right-looking steps
+    on trailing matrices that fit the Infinity Cache): same factorisation, another summation order -- against the plain
+    left-looking path, against the oracle, with a non-positive-definite evaluation and an argument error in the group."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves(Nl, seed=9)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    L = len(Nl)
+    rng = np.random.default_rng(1)
+    delays = np.concatenate([np.zeros((M, 1)), rng.random((M, L - 1)) * 12], 1)
+    alphas = np.tile(alpha, (M, 1)) * (0.7 + 0.6 * rng.random((M, L)))
+    rhos = np.full(M, rho) * (0.5 + rng.random(M))
+    alphas[3, 0] = -1.0
+    with gp.Objective(t, y, s, gp.matern32, precision=prec) as obj:
+        obj.set_option("shared_prefix", 0)
+        obj.set_option("hybrid_tail", 0)
+        ref, rinfo = obj.loglik_batch(delays, alphas, rhos)
+        obj.set_option("hybrid_tail", 1)
+        ll, info = obj.loglik_batch(delays, alphas, rhos)
+        for budget in (40, 4000):            # an early and a late switch to the right-looking form
+            obj.set_option("hybrid_mall_mb", budget)
+            l2, i2 = obj.loglik_batch(delays, alphas, rhos)
+            assert np.array_equal(i2, rinfo) and _rel(l2[rinfo == 0], ref[rinfo == 0]) <= tol, budget
+    assert rinfo[3] == -1 and (np.delete(rinfo, 3) == 0).all() and np.array_equal(info, rinfo)
+    ok = rinfo == 0
+    assert _rel(ll[ok], ref[ok]) <= tol
+    if sum(Nl) <= 2100 and prec == "fp64":
+        o, oi = oracle.loglik_batch("matern32", t, y, s, delays[ok][:6], alphas[ok][:6], rhos[ok][:6], True, nthreads=8)
+        assert (oi == 0).all() and _rel(ll[ok][:6], o) <= LL_RTOL
+
+
 def test_constant_band_zero_prior_variance(gp, oracle):
     """A band of constant fluxes has Sigma_b = 100 var(y_l) = 0: K = delayedCovariance + Sobs (+ B of the other bands) is
     still positive definite and the reference returns a finite log-likelihood.  The fp32 path's capacitance system
@@ -969,6 +1003,7 @@ def test_multi_device_handle_matches_single_device(gp, oracle):
     # (a block of a sharded batch may be shareable where the whole batch is not; its kernels sum in another order)
     with gp.Objective(t, y, s, gp.matern32) as single:
         single.set_option("right_looking_max", 0)
+        single.set_option("hybrid_tail", 0)     # (the step where a group turns right-looking follows its size, which sharding changes)
         single.set_option("shared_prefix", 0)
         ref, rinfo = single.loglik_batch(delays, alphas, rhos)
         fit_ref = single.grid_loglik(delays[:6], 8, seed=3)
@@ -977,6 +1012,7 @@ def test_multi_device_handle_matches_single_device(gp, oracle):
         with gp.Objective(t, y, s, gp.matern32, devices=devs) as multi:
             assert multi.get_option("n_devices") == len(devs) and multi.get_option("gather_mode") == mode
             multi.set_option("right_looking_max", 0)       # applies to every device
+            multi.set_option("hybrid_tail", 0)
             multi.set_option("shared_prefix", 0)
             ll, info = multi.loglik_batch(delays, alphas, rhos)
             assert np.array_equal(ll, ref, equal_nan=True) and np.array_equal(info, rinfo), devs
@@ -1048,6 +1084,7 @@ def test_multi_gpu_rccl_gather_and_foreign_current_device(gp, oracle):
     alphas, rhos = np.tile(alpha, (M, 1)), np.full(M, rho)
     with gp.Objective(t, y, s, gp.matern32) as single:
         single.set_option("right_looking_max", 0)
+        single.set_option("hybrid_tail", 0)     # (the step where a group turns right-looking follows its size, which sharding changes)
         single.set_option("shared_prefix", 0)
         ref, rinfo = single.loglik_batch(delays, alphas, rhos)
         K_ref = single.model_matrix(delays[3], alpha, rho)
@@ -1055,6 +1092,7 @@ def test_multi_gpu_rccl_gather_and_foreign_current_device(gp, oracle):
     with gp.Objective(t, y, s, gp.matern32, devices=devs) as multi:
         assert multi.get_option("gather_mode") == 1          # GPCC_GATHER_RCCL
         multi.set_option("right_looking_max", 0)
+        multi.set_option("hybrid_tail", 0)
         multi.set_option("shared_prefix", 0)
         ll, info = multi.loglik_batch(delays, alphas, rhos)
         assert np.array_equal(ll, ref) and np.array_equal(info, rinfo)
