@@ -179,23 +179,68 @@ __device__ __forceinline__ double gpcc_exp_nonpos(double x)  // x <= 0
     return ldexp(p, (int)nn);
 }
 
-template <int KID>
-__device__ __forceinline__ double gpcc_kernel_eval(double xi, double xj, GpccKernelConst kc)
+// The same to ~1.4 ulp in 11 double-precision operations instead of 19 (the assembly and the fp32 refinement pass are bound by
+// exactly these operations on the fp64 pipe, not by HBM): x = (64 n + j) ln2/64 + r, |r| <= ln2/128, exp(x) = 2^n 2^(j/64) p5(r)
+// with the 64 values of 2^(j/64) in LDS (GPCC_EXP_TABLE_TO_LDS at kernel entry) and a degree-5 polynomial (truncation 4e-17).
+// Worst case against a 60-digit reference over 2e5 arguments in [-700, 0]: 3.1e-16 relative.
+__device__ __constant__ double gpcc_exp_tab_c[64] = {
+    1, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284,
+    1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199,
+    1.0905077326652577, 1.1023825833078409, 1.1143867425958924, 1.1265216186082418,
+    1.1387886347566916, 1.1511892299529827, 1.1637248587775775, 1.1763969916502812,
+    1.189207115002721, 1.2021567314527031, 1.215247359980469, 1.22848053610687,
+    1.241857812073484, 1.2553807570246911, 1.2690509571917332, 1.2828700160787783,
+    1.2968395546510096, 1.3109612115247644, 1.3252366431597413, 1.3396675240533029,
+    1.3542555469368927, 1.3690024229745905, 1.383909881963832, 1.3989796725383112,
+    1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647,
+    1.4768261459394993, 1.4929077282912648, 1.5091644275934228, 1.5255981507445384,
+    1.5422108254079407, 1.5590044002378369, 1.5759808451078865, 1.593142151342267,
+    1.6104903319492543, 1.6280274218573478, 1.6457554781539649, 1.6636765803267364,
+    1.681792830507429, 1.7001063537185235, 1.7186192981224779, 1.7373338352737062,
+    1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989,
+    1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656,
+    1.9152065613971474, 1.9360617934922943, 1.9571441241754002, 1.9784560263879509};
+#define GPCC_EXP_TABLE_TO_LDS(stab, tid)                  \
+    do {                                                   \
+        if ((tid) < 64) (stab)[(tid)] = gpcc_exp_tab_c[(tid)]; \
+    } while (0)
+
+__device__ __forceinline__ double gpcc_exp_nonpos_tab(double x, const double *stab)  // x <= 0; stab: the table in LDS
 {
+    const double INV = 92.332482616893656768, C1 = 0.010830424696223417413, C2 = 2.5728046223276691076e-14;   // 64/ln2; ln2/64 = C1 + C2
+    x = fmax(x, -745.0);                                   // (exp underflows to 0 beyond; keeps the int conversion defined)
+    const double kd = rint(x * INV);
+    double r = fma(-kd, C1, x);                            // C1 has 36 significant bits: kd C1 is exact
+    r = fma(-kd, C2, r);
+    const int ki = (int)kd;
+    double q = 8.3333333333333333333e-03;                  // 1/120
+    q = fma(q, r, 4.1666666666666666667e-02);
+    q = fma(q, r, 1.6666666666666666667e-01);
+    q = fma(q, r, 0.5);
+    q = fma(q, r, 1.0);
+    q = fma(q, r, 1.0);
+    return ldexp(stab[ki & 63] * q, ki >> 6);
+}
+
+template <int KID>
+__device__ __forceinline__ double gpcc_kernel_eval(double xi, double xj, GpccKernelConst kc, const double *stab = nullptr)
+{
+    // stab != NULL (compile-time at every hot call site): the table-based exp; NULL: the polynomial one (utilities)
+    auto ex = [&](double a) { return stab ? gpcc_exp_nonpos_tab(a, stab) : gpcc_exp_nonpos(a); };
     if (KID == 0) {  // OU: exp(-|xi-xj|/rho)
         const double r = fabs(xi - xj);
-        return gpcc_exp_nonpos(-(r * kc.c1));
+        return ex(-(r * kc.c1));
     } else if (KID == 1) {  // rbf
         const double d = xi - xj;
-        return gpcc_exp_nonpos(-((0.5 * (d * d)) * kc.c1));
+        return ex(-((0.5 * (d * d)) * kc.c1));
     } else if (KID == 2) {  // matern32: (1 + sqrt3 r/rho) exp(-sqrt3 r/rho)
         const double r = fabs(xi - xj);
         const double t = (1.7320508075688772 * r) * kc.c1;
-        return (1.0 + t) * gpcc_exp_nonpos(-t);
+        return (1.0 + t) * ex(-t);
     } else {  // matern52: (1 + sqrt5 r/rho + 5 r^2/(3 rho^2)) exp(-sqrt5 r/rho)
         const double r = fabs(xi - xj);
         const double t = (2.23606797749979 * r) * kc.c1;
-        return (1.0 + t + (5.0 * (r * r)) * kc.c2) * gpcc_exp_nonpos(-t);
+        return (1.0 + t + (5.0 * (r * r)) * kc.c2) * ex(-t);
     }
 }
 
@@ -228,7 +273,9 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
     __shared__ __attribute__((aligned(16))) double su[2][GPCC_TILE], sa[2][GPCC_TILE], ssig[GPCC_TILE], ssb[GPCC_MAXL];
     __shared__ int sb[2][GPCC_TILE];
     __shared__ double syv[EXT ? GPCC_TILE : 1];   // fluxes of the tile's columns (explicit 'Y' rows only)
+    __shared__ double sexp[64];                   // 2^(j/64), gpcc_exp_nonpos_tab
     if (tid < GPCC_MAXL) ssb[tid] = (tid < c.L) ? c.sigma_b[tid] : 0.0;
+    GPCC_EXP_TABLE_TO_LDS(sexp, tid);
 
     if (I == first_row && J == 0 && tid == 0) {  // per-slot state + the reference's argument checks
         int bad = 0;
@@ -281,7 +328,7 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
                 typename P::v16 v;
 #pragma unroll
                 for (int h = 0; h < P::EP; ++h) {
-                    const double kv = gpcc_kernel_eval<KID>(ur, su[1][col + h], kc);
+                    const double kv = gpcc_kernel_eval<KID>(ur, su[1][col + h], kc, sexp);
                     v[h] = (T)((ar * sa[1][col + h]) * kv + bt);   // same operations as the general path below
                 }
                 *(typename P::v16 *)(Tt + ch * (GPCC_TILE * P::KC) + r * P::KC + sp * P::EP) = v;
@@ -304,7 +351,7 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
             for (int h = 0; h < P::EP; ++h) {
                 const int cc = col + h;
                 const int bc = sb[1][cc];
-                const double kv = gpcc_kernel_eval<KID>(ur, su[1][cc], kc);  // x - delays[i] vs y - delays[j]
+                const double kv = gpcc_kernel_eval<KID>(ur, su[1][cc], kc, sexp);  // x - delays[i] vs y - delays[j]
                 double val = (ar * sa[1][cc]) * kv;                          // scale[i]*scale[j]*kernel
                 if (diag && r == cc) val = val + sg;                         // + Sobs
                 if (br == bc) val = val + bterm;                             // + B = Q Sigma_b Q'
@@ -1701,6 +1748,8 @@ __global__ __launch_bounds__(256) void gpcc_refine_partials(GpccCtx c, GpccGroup
     __shared__ double su[2][GPCC_TILE], sa[2][GPCC_TILE], ssig[GPCC_TILE], sx[2][GPCC_MAXRHS][GPCC_TILE];
     __shared__ int sb[2][GPCC_TILE];
     __shared__ double sred[4][GPCC_MAXRHS * GPCC_MAXRHS];
+    __shared__ double sexp[64];   // the same exp as the assembly: the elements are regenerated exactly as it computed them
+    GPCC_EXP_TABLE_TO_LDS(sexp, tid);
     {
         const int side = tid >> 7, r = tid & 127;
         const int T0 = side ? J : I, gi = T0 * GPCC_TILE + r;
@@ -1726,7 +1775,7 @@ __global__ __launch_bounds__(256) void gpcc_refine_partials(GpccCtx c, GpccGroup
 #pragma unroll 4
         for (int jj = 0; jj < 64; ++jj) {
             const int j = half * 64 + jj;
-            const double val = (ar * sa[1][j]) * gpcc_kernel_eval<KID>(ur, su[1][j], kc);
+            const double val = (ar * sa[1][j]) * gpcc_kernel_eval<KID>(ur, su[1][j], kc, sexp);
 #pragma unroll
             for (int a = 0; a < GPCC_MAXRHS; ++a)
                 if (a < nrhs) s[a] = fma(val, sx[1][a][j], s[a]);
@@ -1736,7 +1785,7 @@ __global__ __launch_bounds__(256) void gpcc_refine_partials(GpccCtx c, GpccGroup
         for (int jj = 0; jj < 64; ++jj) {
             const int j = half * 64 + jj;
             const int bc = sb[1][j];
-            double val = (ar * sa[1][j]) * gpcc_kernel_eval<KID>(ur, su[1][j], kc);
+            double val = (ar * sa[1][j]) * gpcc_kernel_eval<KID>(ur, su[1][j], kc, sexp);
             if (diag && i == j) val = val + sg;
             if (br < 0 || bc < 0) val = 0.0;   // padding / explicit rows: X is zero there
 #pragma unroll
@@ -1867,10 +1916,13 @@ template <int KID>
 __global__ void gpcc_covariance_kernel(long nx, long ny, const double *xu, const double *xs, const double *yu,
                                        const double *ys, double rho, double *out)
 {
+    __shared__ double sexp[64];   // the assembly's exp (table + degree-5 polynomial): this entry is also how tests reach it
+    GPCC_EXP_TABLE_TO_LDS(sexp, threadIdx.x);
+    __syncthreads();
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nx * ny) return;
     const long r = idx % nx, col = idx / nx;
-    out[idx] = (xs[r] * ys[col]) * gpcc_kernel_eval<KID>(xu[r], yu[col], gpcc_kernel_const<KID>(rho));
+    out[idx] = (xs[r] * ys[col]) * gpcc_kernel_eval<KID>(xu[r], yu[col], gpcc_kernel_const<KID>(rho), sexp);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -86,7 +86,7 @@ int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms
 /* Tunables: "streams" (groups in flight on separate HIP streams, default 1), "slots_per_stream"
  * (evaluations resident per group, default 256 = one diagonal-block workgroup per CU, capped so
  * the workspace stays under 64 GiB), "right_looking_max" (groups of at most this many evaluations use
- * the right-looking update, default 24), "fused_small_max" (groups of at most this many evaluations, default 12, run the
+ * the right-looking update, default 12), "fused_small_max" (groups of at most this many evaluations, default 12, run the
  * trailing update of a step and the next diagonal step in ONE launch: the latency path of a single objective(alpha, rho)),
  * "fused_solve" (1 = default: left-looking groups run the panel solve inside the update kernel and the diagonal tile's update
  * inside the diagonal step -- two launches per step; 0 = the three-kernel path of round 1; results agree to ~1e-13),
@@ -95,20 +95,29 @@ int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms
  * batch whose evaluations all have the same band-1 amplitude, delay and rho -- a fixed-hyper-parameter delay
  * sweep, README.md:172-174 -- and then factorises the tile rows wholly inside band 1 once per group instead of
  * once per evaluation, results bitwise identical; 2 = the caller asserts that property, also for the _device
- * form).  gpcc_get_option also answers "N", "Np", "precision", "bytes_per_slot", "share_tiles", "n_devices",
- * "gather_mode". */
+ * form).  Round 3: "small_n" (1 = default: N <= 191 -- the sizes of the reference's documentation, README.md:156-287 -- runs
+ * the small-N family: ONE launch per batch, one wave per evaluation, the matrix in registers, always fp64 whatever the handle's
+ * precision; 0 = the tile kernels; environment GPCC_SMALL_N sets the default), "hybrid_tail" (1 = default: left-looking groups of
+ * 13-111 evaluations finish right-looking once their trailing matrices fit "hybrid_mall_mb" = 400 MB), "fit_device_unpack" /
+ * "fit_speculate" / "fit_threads" (gpcc_grid_loglik on the small-N path: the kernel unpacks the optimiser's vectors itself;
+ * latency-bound rounds evaluate all four candidate points of an iteration at once; large grids run as up to 4 slices on host
+ * threads, 0 = by size -- none of the three changes a bit of the result).  "right_looking_max" now defaults to 12.
+ * gpcc_get_option also answers "N", "Np", "precision", "bytes_per_slot", "share_tiles", "n_devices", "gather_mode",
+ * "small_n_max" (191), "small_n_active", "small_n_count". */
 int gpcc_set_option(gpcc_handle_t handle, const char *key, long value);
 long gpcc_get_option(gpcc_handle_t handle, const char *key);
 
 /* mu_b[L], Sigma_b[L], resid[N] as precomputed at create (any pointer may be NULL). */
 int gpcc_get_constants(gpcc_handle_t handle, double *mean_b, double *Sigma_b, double *resid);
 
-/* fp32 handles: [sum_i K_ii / d_i, max_i K_ii / d_i] over the Cholesky pivots d_i of each of the first M evaluations
+/* fp32 handles (N >= 192; smaller problems are evaluated in fp64 by the small-N kernels and report zeros here):
+ * [sum_i K_ii / d_i, max_i K_ii / d_i] over the Cholesky pivots d_i of each of the first M evaluations
  * of the last gpcc_loglik_batch / gpcc_loglik_batch_device call (2 M doubles) -- the conditioning measure behind the
  * fp32 accuracy guard.  An fp32 handle (a) refines the quadratic forms r'K^-1 r, Q'K^-1 Q, Q'K^-1 r in fp64 after the
  * fp32 factorisation (one backward solve + one pass over the fp64 elements of K regenerated on the fly: second-order
  * accurate, N^2 work; option "fp32_refine", default 1) and (b) repeats in fp64 -- internally, on a small fp64 workspace
- * it creates on first use -- every evaluation whose mean pivot ratio sum / N exceeds 300 (30 without refinement) or whose
+ * it creates on first use -- every evaluation whose mean pivot ratio sum / N exceeds 300 (30 without refinement), whose LARGEST
+ * ratio exceeds 5e3 (round 3: an adversarial search found evaluations below the mean limit with errors up to 0.6) or whose
  * fp32 factorisation met a non-positive pivot, so that results stay within the 1e-3 bar of fp32 also for
  * ill-conditioned hyper-parameters (calibration: DESIGN.md 4.7).  Options: "fp32_guard" (1 default, 0 = never repeat),
  * "fp32_guard_count" (read-only: evaluations repeated so far).  The guard reads the estimates back, so an fp32
