@@ -179,10 +179,14 @@ __device__ __forceinline__ double gpcc_exp_nonpos(double x)  // x <= 0
     return ldexp(p, (int)nn);
 }
 
-// The same to ~1.4 ulp in 11 double-precision operations instead of 19 (the assembly and the fp32 refinement pass are bound by
-// exactly these operations on the fp64 pipe, not by HBM): x = (64 n + j) ln2/64 + r, |r| <= ln2/128, exp(x) = 2^n 2^(j/64) p5(r)
-// with the 64 values of 2^(j/64) in LDS (GPCC_EXP_TABLE_TO_LDS at kernel entry) and a degree-5 polynomial (truncation 4e-17).
-// Worst case against a 60-digit reference over 2e5 arguments in [-700, 0]: 3.1e-16 relative.
+// The same to ~1.4 ulp in 11 double-precision operations instead of 19: x = (64 n + j) ln2/64 + r, |r| <= ln2/128,
+// exp(x) = 2^n 2^(j/64) p5(r) with the 64 values of 2^(j/64) in LDS (GPCC_EXP_TABLE_TO_LDS at kernel entry) and a degree-5
+// polynomial (truncation 4e-17).  Worst case against a 60-digit reference over 2e5 arguments in [-700, 0]: 3.1e-16 relative.
+// Measured on one box against the polynomial version (profiles/r03/ab_exp_table_vs_polynomial_same_box.log): the fp32 refinement
+// pass 31.3 -> 28.8 ms per 1024 evaluations (its inner loop has LDS bandwidth to spare), but the tile assembly 16.3 -> 17.2 ms and
+// the small-N kernels 0.40 -> 0.42 ms (N = 110) / 1.04 -> 1.15 ms (N = 150) -- the per-lane table gather (bank conflicts, the
+// f64 -> i32 conversion) costs more there than eight fewer FMAs save.  So: the refinement pass and delayedCovariance use it, the
+// assembly and the small-N kernels keep the polynomial.
 __device__ __constant__ double gpcc_exp_tab_c[64] = {
     1, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284,
     1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199,
@@ -226,7 +230,11 @@ template <int KID>
 __device__ __forceinline__ double gpcc_kernel_eval(double xi, double xj, GpccKernelConst kc, const double *stab = nullptr)
 {
     // stab != NULL (compile-time at every hot call site): the table-based exp; NULL: the polynomial one (utilities)
+#ifdef GPCC_AB_POLY_EXP   /* A/B builds only (tools/ab_exp.sh): the round-1 polynomial exp everywhere */
+    auto ex = [&](double a) { return gpcc_exp_nonpos(a); };
+#else
     auto ex = [&](double a) { return stab ? gpcc_exp_nonpos_tab(a, stab) : gpcc_exp_nonpos(a); };
+#endif
     if (KID == 0) {  // OU: exp(-|xi-xj|/rho)
         const double r = fabs(xi - xj);
         return ex(-(r * kc.c1));
@@ -273,9 +281,7 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
     __shared__ __attribute__((aligned(16))) double su[2][GPCC_TILE], sa[2][GPCC_TILE], ssig[GPCC_TILE], ssb[GPCC_MAXL];
     __shared__ int sb[2][GPCC_TILE];
     __shared__ double syv[EXT ? GPCC_TILE : 1];   // fluxes of the tile's columns (explicit 'Y' rows only)
-    __shared__ double sexp[64];                   // 2^(j/64), gpcc_exp_nonpos_tab
     if (tid < GPCC_MAXL) ssb[tid] = (tid < c.L) ? c.sigma_b[tid] : 0.0;
-    GPCC_EXP_TABLE_TO_LDS(sexp, tid);
 
     if (I == first_row && J == 0 && tid == 0) {  // per-slot state + the reference's argument checks
         int bad = 0;
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
                 typename P::v16 v;
 #pragma unroll
                 for (int h = 0; h < P::EP; ++h) {
-                    const double kv = gpcc_kernel_eval<KID>(ur, su[1][col + h], kc, sexp);
+                    const double kv = gpcc_kernel_eval<KID>(ur, su[1][col + h], kc);
                     v[h] = (T)((ar * sa[1][col + h]) * kv + bt);   // same operations as the general path below
                 }
                 *(typename P::v16 *)(Tt + ch * (GPCC_TILE * P::KC) + r * P::KC + sp * P::EP) = v;
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
             for (int h = 0; h < P::EP; ++h) {
                 const int cc = col + h;
                 const int bc = sb[1][cc];
-                const double kv = gpcc_kernel_eval<KID>(ur, su[1][cc], kc, sexp);  // x - delays[i] vs y - delays[j]
+                const double kv = gpcc_kernel_eval<KID>(ur, su[1][cc], kc);  // x - delays[i] vs y - delays[j]
                 double val = (ar * sa[1][cc]) * kv;                          // scale[i]*scale[j]*kernel
                 if (diag && r == cc) val = val + sg;                         // + Sobs
                 if (br == bc) val = val + bterm;                             // + B = Q Sigma_b Q'

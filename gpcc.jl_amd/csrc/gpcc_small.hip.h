@@ -84,7 +84,7 @@ __device__ __forceinline__ void gpcc_small_potf2(const double *sD, double *sX, d
 
 // everything a row needs besides the register blocks (all scalarised after inlining)
 struct GpccSmallState {
-    const double *su, *sa, *ssb, *sexp;
+    const double *su, *sa, *ssb;
     const int *sbd;
     double *sstage, *sD, *sX, *sr;
     const double *sig2, *resid;
@@ -120,7 +120,7 @@ __device__ __forceinline__ void gpcc_small_rows(d4 (&U)[NB][NB], GpccSmallState 
                 for (int r = 0; r < 4; ++r) {
                     const int gr = 16 * J + q + 4 * r;
                     br[r] = st.sbd[gr];
-                    const double kv = gpcc_kernel_eval<KID>(st.su[gr], uc, st.kc, st.sexp);   // kernel(x - delays[i], y - delays[j]; rho)
+                    const double kv = gpcc_kernel_eval<KID>(st.su[gr], uc, st.kc);   // kernel(x - delays[i], y - delays[j]; rho)
                     val[r] = (st.sa[gr] * ac) * kv;                                  // scale[i] scale[j] kernel, delayedCovariance.jl:27
                 }
                 if (i == J) {   // (wave-uniform) + Sobs, marginaliseb.jl:89, :135; padding: 1, right-hand-side row: 0
@@ -224,8 +224,6 @@ __global__ __launch_bounds__(64, WPE) void gpcc_small_eval(GpccCtx c, GpccGroup 
     __shared__ int sbd[NP];                       // band id; -1 padding; -3 the right-hand-side row
     __shared__ double sstage[SB * 4 * 64];
     __shared__ double sD[32 * DLD], sX[16 * DLD], sr[96];   // sD rows 16..31: the identity
-    __shared__ double sexp[64];                               // 2^(j/64) of the table-based exp
-    GPCC_EXP_TABLE_TO_LDS(sexp, lane);
 
     const bool mb = c.marginalise_b != 0;
     for (int p = lane; p < NP; p += 64) {
@@ -245,7 +243,7 @@ __global__ __launch_bounds__(64, WPE) void gpcc_small_eval(GpccCtx c, GpccGroup 
     __syncthreads();
 
     GpccSmallState st;
-    st.su = su; st.sa = sa; st.ssb = ssb; st.sexp = sexp; st.sbd = sbd; st.sstage = sstage; st.sD = sD; st.sX = sX; st.sr = sr;
+    st.su = su; st.sa = sa; st.ssb = ssb; st.sbd = sbd; st.sstage = sstage; st.sD = sD; st.sX = sX; st.sr = sr;
     st.sig2 = c.sig2; st.resid = c.resid; st.kc = gpcc_kernel_const<KID>(rho); st.N = N; st.lane = lane;
     st.py = 1.0; st.quad = 0.0; st.pe = 0; st.bad = 0;
     d4 U[NB][NB];   // finished rows: U[m][i], i > m

@@ -84,9 +84,10 @@ def test_loglik_golden_cases(gp, golden, right_looking_max):
 
 
 def test_device_exp_within_two_ulp_of_libm(gp, oracle):
-    """The device's own exp (2^(j/64) table + degree-5 polynomial, gpcc_exp_nonpos_tab -- assembly, fp32 refinement, small-N
-    kernels, delayedCovariance) against libm through the oracle.  OU with rho = 1, scale 1, delay 0 and y = 0 makes the
-    argument exact (-x), so the comparison is of the exponential alone: <= 2 ulp from 1e-6 to the underflow threshold.
+    """The device's two exps against libm through the oracle: the 2^(j/64) table + degree-5 polynomial (gpcc_exp_nonpos_tab: fp32
+    refinement pass, delayedCovariance) and the degree-13 polynomial (gpcc_exp_nonpos: tile assembly, small-N kernels).  OU with
+    rho = 1, scale 1, delay 0 and one point at 0 makes the argument exact (-x), so the comparison is of the exponential alone:
+    <= 2 ulp from 1e-6 to the underflow threshold.
     (Assembled elements at large r/rho deviate more -- |x| times a few 1e-16 -- because the device multiplies by 1/rho where
     the reference divides: a property of the argument, not of exp, and immaterial at e^-|x|.)"""
     rng = np.random.default_rng(2)
@@ -95,8 +96,21 @@ def test_device_exp_within_two_ulp_of_libm(gp, oracle):
     ref = np.array([oracle.kernel("OU", v, 0.0, 1.0) for v in x])
     ok = ref > 1e-300
     ulp = np.abs(K[ok] - ref[ok]) / np.spacing(ref[ok])
-    print("device exp vs libm: worst %.2f ulp over %d arguments" % (ulp.max(), ok.sum()))
+    print("device exp (table) vs libm: worst %.2f ulp over %d arguments" % (ulp.max(), ok.sum()))
     assert ulp.max() <= 2.0
+    # the assembly's exp: column 0 of the model matrix of one band whose first point sits at 0 (no B term, unit amplitude)
+    for n, fam in ((150, 1), (150, 0), (600, 0)):
+        xs = np.concatenate([[0.0], 10.0 ** rng.uniform(-6, 2.845, n - 1)])
+        with gp.Objective([xs], [np.zeros(n)], [np.ones(n)], gp.OU, marginalise_b=False) as obj:
+            obj.set_option("small_n", fam)
+            col = obj.model_matrix([0.0], [1.0], 1.0)[1:, 0] if not fam else None
+            if fam:   # the small-N kernels have no dense export: their elements are covered by the log-likelihood tests
+                continue
+        refc = np.array([oracle.kernel("OU", v, 0.0, 1.0) for v in xs[1:]])
+        okc = refc > 1e-300
+        ulpc = np.abs(col[okc] - refc[okc]) / np.spacing(refc[okc])
+        print("device exp (polynomial, tile assembly, N = %d) vs libm: worst %.2f ulp" % (n, ulpc.max()))
+        assert ulpc.max() <= 2.0
 
 
 def test_model_matrix_and_factor_vs_oracle(gp, oracle):
