@@ -129,6 +129,7 @@ struct gpcc_handle_s {
     int small_n = 1;         // option "small_n": N <= GPCC_SMALL_MAXN runs gpcc_small_eval (one launch per batch, one wave per evaluation,
                              // the matrix in registers; always fp64) instead of the tile kernels
     std::atomic<long> small_count{0};   // evaluations that took that path so far ("small_n_count")
+    int small_wide_max = 256;           // option "small_wide_max": batches of at most this many evaluations run four waves per evaluation
     int share_tiles = 0;     // tile rows wholly inside band 1
     bool share_now = false;  // decision for the batch being enqueued
     // workspace
@@ -426,6 +427,8 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->fused_solve_min = (int)v;
     } else if (!strcmp(key, "small_n")) {
         h->small_n = v != 0;
+    } else if (!strcmp(key, "small_wide_max")) {
+        h->small_wide_max = (int)v;
     } else if (!strcmp(key, "hybrid_tail")) {
         h->hybrid_tail = v != 0;
     } else if (!strcmp(key, "hybrid_occ")) {
@@ -477,8 +480,9 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "fit_speculate")) return h->fit_speculate;
     if (!strcmp(key, "fit_device_unpack")) return h->fit_device_unpack;
     if (!strcmp(key, "fit_threads")) return h->fit_threads;
-    if (!strcmp(key, "small_n_max")) return GPCC_SMALL_MAXN;
-    if (!strcmp(key, "small_n_active")) return (h->small_n && h->N <= GPCC_SMALL_MAXN) ? 1 : 0;
+    if (!strcmp(key, "small_n_max")) return GPCC_SMALLW_MAXN;
+    if (!strcmp(key, "small_wide_max")) return h->small_wide_max;
+    if (!strcmp(key, "small_n_active")) return (h->small_n && h->N <= GPCC_SMALLW_MAXN) ? 1 : 0;
     if (!strcmp(key, "small_n_count")) return h->small_count;
     if (!strcmp(key, "fp32_guard")) return h->fp32_guard;
     if (!strcmp(key, "fp32_refine")) return h->fp32_refine;
@@ -747,26 +751,7 @@ static int enqueue_factor(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g,
 // The small-N family (gpcc_small.hip.h): N <= GPCC_SMALL_MAXN -- the sizes of the reference's own documentation (N = 110, 150,
 // README.md:156-287) -- is ONE launch per batch on the caller's stream: no workspace, no slots, no groups, no events.
 // ------------------------------------------------------------------------------------------
-static inline bool small_path(const gpcc_handle_t h) { return h->small_n && h->N <= GPCC_SMALL_MAXN; }
-
-template <int KID>
-static void launch_small_kid(int nb, const GpccCtx &c, const GpccGroup &g, hipStream_t s)
-{
-    switch (nb) {
-    case 1: gpcc_small_eval<1, KID, 4><<<g.cnt, 64, 0, s>>>(c, g); break;
-    case 2: gpcc_small_eval<2, KID, 4><<<g.cnt, 64, 0, s>>>(c, g); break;
-    case 3: gpcc_small_eval<3, KID, 4><<<g.cnt, 64, 0, s>>>(c, g); break;
-    case 4: gpcc_small_eval<4, KID, 2><<<g.cnt, 64, 0, s>>>(c, g); break;
-    case 5: gpcc_small_eval<5, KID, 2><<<g.cnt, 64, 0, s>>>(c, g); break;
-    case 6: gpcc_small_eval<6, KID, 2><<<g.cnt, 64, 0, s>>>(c, g); break;
-    case 7: gpcc_small_eval<7, KID, 2><<<g.cnt, 64, 0, s>>>(c, g); break;
-    case 8: gpcc_small_eval<8, KID, 1><<<g.cnt, 64, 0, s>>>(c, g); break;
-    case 9: gpcc_small_eval<9, KID, 1><<<g.cnt, 64, 0, s>>>(c, g); break;
-    case 10: gpcc_small_eval<10, KID, 1><<<g.cnt, 64, 0, s>>>(c, g); break;
-    case 11: gpcc_small_eval<11, KID, 1><<<g.cnt, 64, 0, s>>>(c, g); break;
-    default: gpcc_small_eval<12, KID, 1><<<g.cnt, 64, 0, s>>>(c, g); break;
-    }
-}
+static inline bool small_path(const gpcc_handle_t h) { return h->small_n && h->N <= GPCC_SMALLW_MAXN; }
 
 // d_xpar != NULL: requests of the optimiser (M x (L+1) unconstrained vectors, unpacked on the device; d_delays is then the
 // candidate-delay table and d_xrow[i] the row of evaluation i)
@@ -782,16 +767,18 @@ static int enqueue_small(gpcc_handle_t h, int M, const double *d_delays, const d
     g.first = 0; g.slot0 = 0; g.cnt = M; g.spread = 0;
     g.xpar = d_xpar; g.xrow = d_xrow; g.rhomin = rhomin; g.rhomax = rhomax;
     const int nb = (h->N + 1 + 15) / 16;   // the matrix bordered by the right-hand side, in 16 x 16 blocks
+    // one wave per evaluation where that fits (N <= 191) and the batch is large enough to fill the SIMDs; four waves per
+    // evaluation for N = 192 .. 383, and for batches of at most small_wide_max evaluations (latency-bound: optimiser rounds)
+    const bool wide = nb > GPCC_SMALL_MAXNB || (M <= h->small_wide_max && nb >= 5);
+    hipError_t e = hipSuccess;
     {
         ProfScope pr(h, GPCC_PROF_SMALL_EVAL, caller);
-        switch (h->kernel_id) {
-        case 0: launch_small_kid<0>(nb, c, g, caller); break;
-        case 1: launch_small_kid<1>(nb, c, g, caller); break;
-        case 2: launch_small_kid<2>(nb, c, g, caller); break;
-        default: launch_small_kid<3>(nb, c, g, caller); break;
-        }
+        typedef hipError_t (*launch_t)(int, const GpccCtx &, const GpccGroup &, hipStream_t);
+        static const launch_t narrow[4] = {gpcc_small_launch_0, gpcc_small_launch_1, gpcc_small_launch_2, gpcc_small_launch_3};
+        static const launch_t four[4] = {gpcc_smallw_launch_0, gpcc_smallw_launch_1, gpcc_smallw_launch_2, gpcc_smallw_launch_3};
+        e = (wide ? four : narrow)[h->kernel_id & 3](nb, c, g, caller);
     }
-    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) return fail(h, GPCC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     h->small_count += M;
     return 0;

@@ -10,6 +10,7 @@
 // linear copy.  A row of tiles (I,0..I) is contiguous, so both operand streams of the left-looking update
 // are purely sequential reads.
 #pragma once
+// (non-template kernels are `static`: this header is compiled into several objects, gpcc.jl_amd/build.py)
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -187,7 +188,7 @@ __device__ __forceinline__ double gpcc_exp_nonpos(double x)  // x <= 0
 // the small-N kernels 0.40 -> 0.42 ms (N = 110) / 1.04 -> 1.15 ms (N = 150) -- the per-lane table gather (bank conflicts, the
 // f64 -> i32 conversion) costs more there than eight fewer FMAs save.  So: the refinement pass and delayedCovariance use it, the
 // assembly and the small-N kernels keep the polynomial.
-__device__ __constant__ double gpcc_exp_tab_c[64] = {
+static __device__ __constant__ double gpcc_exp_tab_c[64] = {   // (static: the header is compiled into several objects)
     1, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284,
     1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199,
     1.0905077326652577, 1.1023825833078409, 1.1143867425958924, 1.1265216186082418,
@@ -1818,7 +1819,7 @@ __global__ __launch_bounds__(256) void gpcc_refine_partials(GpccCtx c, GpccGroup
 
 // gpcc_refine_finish: G = X'R + R'X - X' K0 X  (R = [Q | Y - bbar] in woodbury mode, else Y - bbar), then the same
 // log-likelihood arithmetic as the last diagonal step, whose outputs it replaces.   grid cnt, block 256.
-__global__ __launch_bounds__(256) void gpcc_refine_finish(GpccCtx c, GpccGroup g)
+static __global__ __launch_bounds__(256) void gpcc_refine_finish(GpccCtx c, GpccGroup g)
 {
     const int m = blockIdx.x, slot = g.slot0 + m, tid = threadIdx.x, nrhs = c.nrhs, n2 = nrhs * nrhs;
     if (c.info[slot] != 0 || gpcc_leader_failure(c, g) != 0) return;   // the diagonal kernel has reported the failure
@@ -1934,7 +1935,7 @@ __global__ void gpcc_covariance_kernel(long nx, long ny, const double *xu, const
 // ------------------------------------------------------------------------------------------
 // getprobabilities (src/getprobabilities.jl:10-20): exp(joint - logsumexp(joint)), one block.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void gpcc_probabilities_kernel(int G, const double *ll, const double *lp,
+static __global__ __launch_bounds__(1024) void gpcc_probabilities_kernel(int G, const double *ll, const double *lp,
                                                                   double *out)
 {
     __shared__ double red[1024];
@@ -1967,7 +1968,7 @@ __global__ __launch_bounds__(1024) void gpcc_probabilities_kernel(int G, const d
 // ------------------------------------------------------------------------------------------
 // self-test: f64 MFMA fragment maps with asymmetric integer data, and a rate probe.
 // ------------------------------------------------------------------------------------------
-__global__ void gpcc_selftest_map(const double *A /*16x4 row-major*/, const double *B /*4x16 row-major*/,
+static __global__ void gpcc_selftest_map(const double *A /*16x4 row-major*/, const double *B /*4x16 row-major*/,
                                   double *D /*16x16 row-major*/)
 {
     const int lane = threadIdx.x & 63, lr = lane & 15, q = lane >> 4;
@@ -1976,7 +1977,7 @@ __global__ void gpcc_selftest_map(const double *A /*16x4 row-major*/, const doub
     for (int r = 0; r < 4; ++r) D[(q + 4 * r) * 16 + lr] = acc[r];
 }
 
-__global__ __launch_bounds__(256) void gpcc_selftest_rate(double *sink, int iters)
+static __global__ __launch_bounds__(256) void gpcc_selftest_rate(double *sink, int iters)
 {
     d4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
     const double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
@@ -1990,7 +1991,7 @@ __global__ __launch_bounds__(256) void gpcc_selftest_rate(double *sink, int iter
     if (s[0] + s[1] + s[2] + s[3] == 12345.678) sink[0] = s[0];
 }
 
-__global__ void gpcc_selftest_map_f32(const float *A /*16x4 row-major*/, const float *B /*4x16 row-major*/,
+static __global__ void gpcc_selftest_map_f32(const float *A /*16x4 row-major*/, const float *B /*4x16 row-major*/,
                                       float *D /*16x16 row-major*/)
 {
     const int lane = threadIdx.x & 63, lr = lane & 15, q = lane >> 4;

@@ -33,8 +33,10 @@
 #include "gpcc_kernels.hip.h"
 #include "gpcc_transforms.h"
 
-#define GPCC_SMALL_MAXNB 12                      /* bordered size N + 1 <= 192 */
+#define GPCC_SMALL_MAXNB 12                      /* one wave per evaluation: bordered size N + 1 <= 192 */
 #define GPCC_SMALL_MAXN (16 * GPCC_SMALL_MAXNB - 1)
+#define GPCC_SMALLW_MAXNB 24                     /* four waves per evaluation: N + 1 <= 384 */
+#define GPCC_SMALLW_MAXN (16 * GPCC_SMALLW_MAXNB - 1)
 #define GPCC_SMALL_DLD 17
 
 __device__ __forceinline__ void gpcc_small_potf2(const double *sD, double *sX, double *sr, const int lane, const bool last,
@@ -94,6 +96,42 @@ struct GpccSmallState {
     int pe, bad;       // sum of their exponents; order of the first non-positive pivot
 };
 
+// the four elements a lane holds of block (J, i), J <= i, of K bordered (row 16 J + q + 4 r, column 16 i + lr)
+template <int KID, int NP>
+__device__ __forceinline__ void gpcc_small_block(const GpccSmallState &st, const int J, const int i, double (&val)[4])
+{
+    const int lane = st.lane, lr = lane & 15, q = lane >> 4, N = st.N;
+    const int gc = 16 * i + lr;
+    const double uc = st.su[gc], ac = st.sa[gc];
+    const int bc = st.sbd[gc];
+    const bool edge = 16 * i + 15 >= N;   // the block holds the right-hand side and/or padding (wave-uniform)
+    int br[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int gr = 16 * J + q + 4 * r;
+        br[r] = st.sbd[gr];
+        const double kv = gpcc_kernel_eval<KID>(st.su[gr], uc, st.kc);   // kernel(x - delays[i], y - delays[j]; rho)
+        val[r] = (st.sa[gr] * ac) * kv;                                  // scale[i] scale[j] kernel, delayedCovariance.jl:27
+    }
+    if (i == J) {   // (wave-uniform) + Sobs, marginaliseb.jl:89, :135; padding: 1, right-hand-side row: 0
+        const double sgc = gc < N ? st.sig2[gc] : (gc == NP - 1 ? 0.0 : 1.0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (q + 4 * r == lr) val[r] = val[r] + sgc;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)   // + B = Q Sigma_b Q' (same band), marginaliseb.jl:96, :135
+        val[r] = val[r] + ((br[r] == bc && bc >= 0) ? st.ssb[gc] : 0.0);
+    if (edge) {     // (wave-uniform) the last column = Y - bbar, and its mirror inside the last diagonal block
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gr = 16 * J + q + 4 * r;
+            if (bc == -3 && br[r] >= 0) val[r] = st.resid[gr];
+            if (br[r] == -3 && bc >= 0) val[r] = st.resid[gc];
+        }
+    }
+}
+
 // rows J .. NB-1 by compile-time recursion (a `#pragma unroll` of this loop is refused beyond ~16k IR instructions)
 template <int NB, int KID, int J>
 __device__ __forceinline__ void gpcc_small_rows(d4 (&U)[NB][NB], GpccSmallState &st)
@@ -102,7 +140,7 @@ __device__ __forceinline__ void gpcc_small_rows(d4 (&U)[NB][NB], GpccSmallState 
         typedef GpccPrec<double> PD;
         constexpr int NP = 16 * NB, DLD = GPCC_SMALL_DLD;
         constexpr int SB = (NB + 1) / 2;   // blocks per staging pass (a row is assembled in at most two)
-        const int lane = st.lane, lr = lane & 15, q = lane >> 4, N = st.N;
+        const int lane = st.lane, lr = lane & 15, q = lane >> 4;
         d4 T[NB];
         // ---- (a) row J of S = -(K bordered): blocks (J, i), i >= J, through the LDS stage
 #pragma unroll
@@ -110,36 +148,8 @@ __device__ __forceinline__ void gpcc_small_rows(d4 (&U)[NB][NB], GpccSmallState 
             const int i1 = (i0 + SB < NB) ? i0 + SB : NB;
 #pragma nounroll
             for (int i = i0; i < i1; ++i) {
-                const int gc = 16 * i + lr;
-                const double uc = st.su[gc], ac = st.sa[gc];
-                const int bc = st.sbd[gc];
-                const bool edge = 16 * i + 15 >= N;   // the block holds the right-hand side and/or padding (wave-uniform)
                 double val[4];
-                int br[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gr = 16 * J + q + 4 * r;
-                    br[r] = st.sbd[gr];
-                    const double kv = gpcc_kernel_eval<KID>(st.su[gr], uc, st.kc);   // kernel(x - delays[i], y - delays[j]; rho)
-                    val[r] = (st.sa[gr] * ac) * kv;                                  // scale[i] scale[j] kernel, delayedCovariance.jl:27
-                }
-                if (i == J) {   // (wave-uniform) + Sobs, marginaliseb.jl:89, :135; padding: 1, right-hand-side row: 0
-                    const double sgc = gc < N ? st.sig2[gc] : (gc == NP - 1 ? 0.0 : 1.0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (q + 4 * r == lr) val[r] = val[r] + sgc;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r)   // + B = Q Sigma_b Q' (same band), marginaliseb.jl:96, :135
-                    val[r] = val[r] + ((br[r] == bc && bc >= 0) ? st.ssb[gc] : 0.0);
-                if (edge) {     // (wave-uniform) the last column = Y - bbar, and its mirror inside the last diagonal block
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int gr = 16 * J + q + 4 * r;
-                        if (bc == -3 && br[r] >= 0) val[r] = st.resid[gr];
-                        if (br[r] == -3 && bc >= 0) val[r] = st.resid[gc];
-                    }
-                }
+                gpcc_small_block<KID, NP>(st, J, i, val);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) st.sstage[((i - i0) * 4 + r) * 64 + lane] = -val[r];
             }
@@ -256,3 +266,227 @@ __global__ __launch_bounds__(64, WPE) void gpcc_small_eval(GpccCtx c, GpccGroup 
         g.out_info[g.first + m] = st.bad;
     }
 }
+
+
+// ------------------------------------------------------------------------------------------
+// gpcc_smallw_eval<NB, KID, W, WGS>: the same row-wise algorithm with ONE WORKGROUP OF W WAVES per evaluation, for
+//  * 192 <= N <= 383 (NB <= 24): the live rectangle of the row-wise form -- up to NB^2/4 blocks -- no longer fits one wave's 512
+//    registers but fits a CU's register file (4 waves x 512; rounds 1-2 and the first version of this round sent these sizes to the
+//    tile kernels: 1.7 M evaluations/s at N = 192-256 against 8.3 M/s at N = 191, profiles/r03/size_sweep_64_to_1024.log);
+//  * latency-bound batches of any smaller N (a Nelder-Mead round over a README-size grid is 100-800 evaluations: a fraction of the
+//    chip's 1024 SIMDs): the assembly and the MFMAs of an evaluation run on four SIMDs instead of one.
+// Block column i belongs to wave i % W: that wave assembles T[i], applies the finished rows to it, and keeps U[m][i] in its registers.
+// Row J:   the owner of column J publishes U[0..J-1][J] (lane-private image: the A-operand of a transposed block is a lane's own
+//          registers) in LDS  |  every wave: assemble its T[i], i >= J (own LDS stage)  || barrier ||
+//          every wave: T[i] += sum_m U[m][J]' U[m][i] (A from LDS, B from registers) -- the owner: column J first, then the
+//          16 x 16 step on -T[J] while the others work on their columns  || barrier ||  U[J][i] = (-inv(L_D)) T[i], i > J.
+// Two barriers per row.  The running product behind sum log L_ii travels from owner to owner through LDS, so the result is the
+// one-wave kernel's bit for bit (an evaluation must not depend on the batch it travels in: the optimiser relies on it); the first
+// non-positive pivot stops every wave at the row's second barrier.
+// LDS (dynamic): point data 28 NP bytes, column buffer (NB - 1) x 2 KiB, W stages of ceil(NB / W) x 2 KiB, the diagonal step.
+// ------------------------------------------------------------------------------------------
+template <int NB, int W>
+struct GpccSmallWLds {
+    static constexpr int NP = 16 * NB, NC = (NB + W - 1) / W, DLD = GPCC_SMALL_DLD;
+    static constexpr int o_su = 0, o_sa = o_su + NP, o_ssb = o_sa + NP, o_col = o_ssb + NP, o_stage = o_col + (NB - 1) * 256,
+                         o_sD = o_stage + W * NC * 256, o_sX = o_sD + 32 * DLD, o_sr = o_sX + 16 * DLD, o_red = o_sr + 96,
+                         o_sal = o_red + 2 * W + 2, o_end = o_sal + GPCC_MAXL;   // in doubles
+    static constexpr int bytes = o_end * 8 + NP * 4 + 16;                        // + band ids (int) + flags
+};
+
+template <int NB, int KID, int W, int J>
+__device__ __forceinline__ void gpcc_smallw_rows(d4 (&U)[NB][(NB + W - 1) / W], GpccSmallState &st, double *scol, double *sred, int *sflag, const int w)
+{
+    if constexpr (J < NB) {
+        typedef GpccPrec<double> PD;
+        constexpr int NP = 16 * NB, NC = (NB + W - 1) / W, DLD = GPCC_SMALL_DLD;
+        constexpr int owner = J % W, cJ = J / W;          // wave and local column of block column J
+        const int lane = st.lane, lr = lane & 15, q = lane >> 4;
+        d4 T[NC];
+        // ---- the owner publishes column J: U[m][J], m < J, as lane-private images
+        if (w == owner) {
+#pragma unroll
+            for (int mm = 0; mm < J; ++mm)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) scol[(mm * 4 + s) * 64 + lane] = U[mm][cJ][s];
+        }
+        // ---- (a) this wave's blocks of row J: columns i = c W + w >= J, through its own LDS stage
+        {
+            const int c0 = (J > w) ? (J - w + W - 1) / W : 0;
+#pragma nounroll
+            for (int c = c0; c < NC; ++c) {
+                const int i = c * W + w;
+                if (i >= NB) break;
+                double val[4];
+                gpcc_small_block<KID, NP>(st, J, i, val);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st.sstage[(c * 4 + r) * 64 + lane] = -val[r];
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (c * W + w >= J && c * W + w < NB) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T[c][r] = st.sstage[(c * 4 + r) * 64 + lane];
+                }
+        }
+        __syncthreads();   // column J is published
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- (b) T[i] += sum_{m<J} U[m][J]' U[m][i]; the owner takes column J first and factors it
+        auto apply = [&](const bool only_cJ, const bool skip_cJ) {
+#pragma unroll
+            for (int mm = 0; mm < J; ++mm) {
+                double a[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) a[s] = scol[(mm * 4 + s) * 64 + lane];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    if (c * W + W - 1 < J) continue;                 // (compile time) no wave's column c reaches row J
+                    if ((only_cJ && c != cJ) || (skip_cJ && c == cJ)) continue;
+                    if (c * W + w >= J && c * W + w < NB) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) T[c] = PD::mfma(a[s], U[mm][c][s], T[c]);
+                    }
+                }
+            }
+        };
+        if (w == owner) {
+            apply(true, false);
+            // ---- (c) the diagonal block: 16 x 16 potf2 + inverse, while the other waves update their columns
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st.sD[(q + 4 * r) * DLD + lr] = -T[cJ][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_sched_barrier(0);
+            // the running product of the pivots' reciprocal roots travels from owner to owner (sred[0..1]): the SAME sequence of
+            // multiplications as in the one-wave kernel, so both kernels return the same bits
+            st.py = sred[0];
+            st.pe = (int)sred[1];
+            gpcc_small_potf2(st.sD, st.sX, st.sr, lane, J == NB - 1, 16 * J, st.py, st.pe, st.bad, st.quad);
+            __builtin_amdgcn_sched_barrier(0);
+            if (lane == 0) {
+                sred[0] = st.py;
+                sred[1] = (double)st.pe;
+                if (J == NB - 1) sred[2] = st.quad;
+                if (st.bad) *sflag = st.bad;
+            }
+            if constexpr (J < NB - 1) apply(false, true);
+        } else {
+            if constexpr (J < NB - 1) apply(false, false);
+        }
+        __syncthreads();   // -inv(L_D) (and a failure, if any) is published; everybody is done with column J's images
+        if (*sflag) return;
+        if constexpr (J < NB - 1) {
+            // ---- (d) U[J][i] = (-inv(L_D)) T[i], i > J
+            double ax[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ax[s] = st.sX[lr * DLD + q + 4 * s];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (c * W + W - 1 <= J) continue;                    // (compile time)
+                if (c * W + w > J && c * W + w < NB) {
+                    d4 o = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) o = PD::mfma(ax[s], T[c][s], o);
+                    U[J][c] = o;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            gpcc_smallw_rows<NB, KID, W, J + 1>(U, st, scol, sred, sflag, w);
+        }
+    }
+}
+
+template <int NB, int KID, int W, int WGS>
+__global__ __launch_bounds__(64 * W, WGS) void gpcc_smallw_eval(GpccCtx c, GpccGroup g)
+{
+    typedef GpccSmallWLds<NB, W> LD;
+    constexpr int NP = LD::NP, NC = LD::NC, DLD = LD::DLD;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int m = blockIdx.x;
+    if (m >= g.cnt) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = c.N;
+    double *su = lds + LD::o_su, *sa = lds + LD::o_sa, *ssb = lds + LD::o_ssb, *scol = lds + LD::o_col;
+    double *sstage = lds + LD::o_stage + w * NC * 256, *sD = lds + LD::o_sD, *sX = lds + LD::o_sX, *sr = lds + LD::o_sr;
+    double *sred = lds + LD::o_red, *sal = lds + LD::o_sal;
+    int *sbd = (int *)(lds + LD::o_end), *sflag = sbd + NP;
+    const double *delays;
+    double rho;
+    if (g.xpar) {   // a request of the optimiser: unpack here (bit-identical to the host's gpcc_unpack_params)
+        const double *x = g.xpar + (long)(g.first + m) * (c.L + 1);
+        delays = g.delays + (long)g.xrow[g.first + m] * c.L;
+        if (tid < c.L) sal[tid] = gpcctf::makepositive(x[tid]) + 1e-8;             // makeα, marginaliseb.jl:112
+        rho = gpcctf::transformbetween(x[c.L], g.rhomin, g.rhomax);                // makeρ, :114
+    } else {
+        delays = g.delays + (long)(g.first + m) * c.L;
+        if (tid < c.L) sal[tid] = g.alpha[(long)(g.first + m) * c.L + tid];
+        rho = g.rho[g.first + m];
+    }
+    if (tid == 0) {
+        *sflag = 0;
+        sred[0] = 1.0;   // running product of the mantissas of 1 / sqrt(d_j) ...
+        sred[1] = 0.0;   // ... and the sum of their exponents
+        sred[2] = 0.0;   // r' K^-1 r
+    }
+    __syncthreads();
+    {   // the reference's argument checks (delayedCovariance.jl:3, :5-7)
+        int badarg = 0;
+        for (int l = 0; l < c.L; ++l)
+            if (!(sal[l] > 0.0)) badarg = -1;
+        if (badarg == 0 && rho <= 0.0) badarg = -2;
+        if (badarg) {
+            if (tid == 0) {
+                g.out_loglik[g.first + m] = __builtin_nan("");
+                g.out_info[g.first + m] = badarg;
+            }
+            return;
+        }
+    }
+    const bool mb = c.marginalise_b != 0;
+    for (int p = tid; p < NP; p += 64 * W) {
+        int b = -1;
+        double u = 0.0, a = 0.0, sb = 0.0;
+        if (p < N) {
+            b = c.band[p];
+            u = c.t[p] - delays[b];            // x - delays[i], delayedCovariance.jl:27
+            a = sal[b];
+            sb = mb ? c.sigma_b[b] : 0.0;      // B = Q Sigma_b Q', marginaliseb.jl:96, :135
+        } else if (p == NP - 1) {              // the right-hand side: always the LAST row / column
+            b = -3;
+        }
+        sbd[p] = b; su[p] = u; sa[p] = a; ssb[p] = sb;
+    }
+    for (int e = tid; e < 16 * DLD; e += 64 * W) sD[16 * DLD + e] = (e / DLD == e % DLD) ? 1.0 : 0.0;
+    __syncthreads();
+
+    GpccSmallState st;
+    st.su = su; st.sa = sa; st.ssb = ssb; st.sbd = sbd; st.sstage = sstage; st.sD = sD; st.sX = sX; st.sr = sr;
+    st.sig2 = c.sig2; st.resid = c.resid; st.kc = gpcc_kernel_const<KID>(rho); st.N = N; st.lane = lane;
+    st.py = 1.0; st.quad = 0.0; st.pe = 0; st.bad = 0;
+    d4 U[NB][NC];
+    gpcc_smallw_rows<NB, KID, W, 0>(U, st, scol, sred, sflag, w);
+    __syncthreads();
+    if (tid == 0) {
+        const int bad = *sflag;
+        const double log2pi = 1.8378770664093454835606594728112;
+        const double ld = -(log(sred[0]) + (double)(int)sred[1] * 0.69314718055994530942);   // sum log L_ii
+        g.out_loglik[g.first + m] = bad ? __builtin_nan("") : -((double)N * log2pi + 2.0 * ld) / 2.0 - sred[2] / 2.0;
+        g.out_info[g.first + m] = bad;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Launchers.  The instantiations live in gpcc_small_inst.hip, which build.py compiles once per (family, kernel id) in parallel
+// (8 objects; as one translation unit with gpcc_hip.hip the library took 7.5 minutes to build): gpcc_hip.hip only sees these.
+// nb = number of 16 x 16 blocks of the bordered matrix.  hipSuccess, or the error of the attribute call / launch.
+// ------------------------------------------------------------------------------------------
+hipError_t gpcc_small_launch_0(int nb, const GpccCtx &c, const GpccGroup &g, hipStream_t s);
+hipError_t gpcc_small_launch_1(int nb, const GpccCtx &c, const GpccGroup &g, hipStream_t s);
+hipError_t gpcc_small_launch_2(int nb, const GpccCtx &c, const GpccGroup &g, hipStream_t s);
+hipError_t gpcc_small_launch_3(int nb, const GpccCtx &c, const GpccGroup &g, hipStream_t s);
+hipError_t gpcc_smallw_launch_0(int nb, const GpccCtx &c, const GpccGroup &g, hipStream_t s);
+hipError_t gpcc_smallw_launch_1(int nb, const GpccCtx &c, const GpccGroup &g, hipStream_t s);
+hipError_t gpcc_smallw_launch_2(int nb, const GpccCtx &c, const GpccGroup &g, hipStream_t s);
+hipError_t gpcc_smallw_launch_3(int nb, const GpccCtx &c, const GpccGroup &g, hipStream_t s);

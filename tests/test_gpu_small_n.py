@@ -30,12 +30,12 @@ def _params(rng, M, L):
     return delays, rng.uniform(0.4, 3.0, (M, L)), rng.uniform(0.5, 8.0, M)
 
 
-def test_small_path_is_the_default_up_to_191_points(gp):
+def test_small_path_is_the_default_up_to_383_points(gp):
     rng = np.random.default_rng(1)
-    for n, active in ((1, 1), (110, 1), (150, 1), (159, 1), (160, 1), (191, 1), (192, 0), (300, 0)):
+    for n, active in ((1, 1), (110, 1), (150, 1), (191, 1), (192, 1), (300, 1), (383, 1), (384, 0), (500, 0)):
         t, y, s = _problem(rng, [n])
         with gp.Objective(t, y, s, "OU", marginalise_b=False) as obj:
-            assert obj.get_option("small_n_max") == 191
+            assert obj.get_option("small_n_max") == 383
             assert obj.get_option("small_n_active") == active, n
             obj.loglik_batch(np.zeros((3, 1)), np.ones((3, 1)), np.full(3, 2.0))
             assert obj.get_option("small_n_count") == (3 if active else 0)
@@ -69,6 +69,52 @@ def test_every_size_1_to_191_vs_oracle_and_tile_path(gp, oracle):
         worst_t = max(worst_t, np.max(np.abs(ll - ll_t) / np.abs(ll_t)))
         assert worst_o <= 1e-9 and worst_t <= 1e-11, (N, Nl, kname, mb, worst_o, worst_t)
     print("N = 1..191: worst vs oracle %.2e, worst vs tile kernels %.2e" % (worst_o, worst_t))
+
+
+def test_four_waves_per_evaluation_sizes_192_to_383_and_small_batches(gp, oracle):
+    """gpcc_smallw_eval: (a) N = 192 .. 383 (every instantiated block count, sizes on and off a 16-block edge) against the oracle
+    and the tile kernels; (b) N <= 191 in batches small enough to take the four-wave kernel against the one-wave kernel (same
+    factorisation; sum log L_ii is combined across waves in another order: <= 1e-13)."""
+    rng = np.random.default_rng(17)
+    worst_o = worst_t = 0.0
+    for N in (192, 199, 207, 208, 223, 224, 239, 255, 256, 271, 287, 300, 303, 319, 320, 335, 351, 352, 367, 382, 383):
+        L = 1 + N % 3
+        cuts = np.sort(rng.choice(np.arange(2, N - 1), L - 1, replace=False)) if L > 1 else np.array([], dtype=int)
+        Nl = [int(x) for x in np.diff(np.concatenate([[0], cuts, [N]]))]
+        mb = bool(N % 2) and min(Nl) >= 2
+        kname = KNAMES[N % 4]
+        t, y, s = _problem(rng, Nl)
+        delays, alpha, rho = _params(rng, 5, L)
+        alpha[4, 0] = -1.0
+        ref, rinfo = oracle.loglik_batch(kname, t, y, s, delays, alpha, rho, mb, nthreads=5)
+        with gp.Objective(t, y, s, kname, marginalise_b=mb) as obj:
+            assert obj.get_option("small_n_active") == 1
+            ll, info = obj.loglik_batch(delays, alpha, rho)
+            obj.set_option("small_n", 0)
+            ll_t, info_t = obj.loglik_batch(delays, alpha, rho)
+        assert np.array_equal(info, rinfo) and np.array_equal(info_t, rinfo) and rinfo[4] == -1 and (rinfo[:4] == 0).all(), (N, info, rinfo)
+        worst_o = max(worst_o, np.max(np.abs(ll[:4] - ref[:4]) / np.abs(ref[:4])))
+        worst_t = max(worst_t, np.max(np.abs(ll[:4] - ll_t[:4]) / np.abs(ll_t[:4])))
+        assert worst_o <= 1e-9 and worst_t <= 1e-11, (N, Nl, kname, mb, worst_o, worst_t)
+    print("N = 192..383 (four waves per evaluation): worst vs oracle %.2e, vs tile kernels %.2e" % (worst_o, worst_t))
+    worst = 0.0
+    for N in (64, 79, 110, 111, 112, 150, 159, 176, 191):
+        t, y, s = _problem(rng, [N - N // 2, N // 2])
+        delays, alpha, rho = _params(rng, 40, 2)
+        with gp.Objective(t, y, s, KNAMES[N % 4]) as obj:
+            obj.set_option("small_wide_max", 0)          # one wave per evaluation
+            a, ia = obj.loglik_batch(delays, alpha, rho)
+            obj.set_option("small_wide_max", 256)        # four waves per evaluation for this batch of 40
+            b, ib = obj.loglik_batch(delays, alpha, rho)
+        assert (ia == 0).all() and (ib == 0).all()
+        assert np.array_equal(a, b), N
+    # a not-positive-definite evaluation stops all four waves (duplicated time, no noise, no B term)
+    n = 300
+    tt = [np.sort(rng.uniform(0, 20, n))]
+    tt[0][200] = tt[0][199]
+    with gp.Objective(tt, [rng.standard_normal(n)], [np.zeros(n)], "rbf", marginalise_b=False) as obj:
+        ll, info = obj.loglik_batch([[0.0]], [[1.0]], [30.0])
+    assert info[0] > 0 and np.isnan(ll[0])
 
 
 def test_golden_cases_on_the_small_path(gp, golden):
