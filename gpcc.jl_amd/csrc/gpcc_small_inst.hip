@@ -63,8 +63,8 @@ hipError_t GPCC_CAT(gpcc_smallw_launch_, GPCC_INST_KID)(int nb, const GpccCtx &c
     default: break;
     }
     if (nb < 5) return hipErrorInvalidValue;   // (the caller sends such sizes to the one-wave kernels)
-    if (nb <= 14) return launch_one<14, 1>(c, g, s);
-    if (nb <= 16) return launch_one<16, 1>(c, g, s);
+    if (nb <= 14) return launch_one<14, 2>(c, g, s);
+    if (nb <= 16) return launch_one<16, 2>(c, g, s);
     if (nb <= 18) return launch_one<18, 1>(c, g, s);
     if (nb <= 20) return launch_one<20, 1>(c, g, s);
     if (nb <= 22) return launch_one<22, 1>(c, g, s);
