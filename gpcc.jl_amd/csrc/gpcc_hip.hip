@@ -129,7 +129,7 @@ struct gpcc_handle_s {
     int small_n = 1;         // option "small_n": N <= GPCC_SMALL_MAXN runs gpcc_small_eval (one launch per batch, one wave per evaluation,
                              // the matrix in registers; always fp64) instead of the tile kernels
     std::atomic<long> small_count{0};   // evaluations that took that path so far ("small_n_count")
-    int small_wide_max = 256;           // option "small_wide_max": batches of at most this many evaluations run four waves per evaluation
+    int small_wide_max = 512;           // option "small_wide_max": batches of at most this many evaluations (two workgroups per CU) run four waves per evaluation
     int share_tiles = 0;     // tile rows wholly inside band 1
     bool share_now = false;  // decision for the batch being enqueued
     // workspace
