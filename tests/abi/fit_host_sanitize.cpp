@@ -38,6 +38,20 @@ int main()
         std::printf("rosenbrock: %ld of %ld converged, %lld evaluations in %lld rounds\n", good, P, nm.f_calls, nm.rounds);
         if (good < P * 9 / 10) return 2;
     }
+    {   // speculative rounds (round 3): the same trajectories as the plain rounds, bit for bit, in fewer rounds
+        const long P = 61;
+        std::vector<double> x0(P * 2), xa(P * 2), fa(P), xb(P * 2), fb(P);
+        gpccfit::Rng rg(9);
+        for (auto &v : x0) v = 4.0 * rg.uniform() - 2.0;
+        gpccfit::BatchedNelderMead plain(P, 2, 500, 1e-10), spec(P, 2, 500, 1e-10);
+        spec.speculate_max = 1024;
+        if (plain.run(rosen, nullptr, x0.data(), xa.data(), fa.data()) || spec.run(rosen, nullptr, x0.data(), xb.data(), fb.data())) return 8;
+        for (long p = 0; p < P; ++p)
+            if (fa[p] != fb[p] || xa[2 * p] != xb[2 * p] || xa[2 * p + 1] != xb[2 * p + 1] || plain.it[p] != spec.it[p]) return 9;
+        std::printf("speculative rounds: %lld rounds instead of %lld, %lld evaluations instead of %lld\n", spec.rounds, plain.rounds,
+                    spec.f_calls, plain.f_calls);
+        if (!(spec.rounds < plain.rounds && spec.f_calls > plain.f_calls)) return 10;
+    }
     {
         const long P = 31;
         std::vector<double> x0(P * 5, 1.0), xmin(P * 5), fmin(P);

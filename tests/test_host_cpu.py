@@ -86,6 +86,7 @@ def test_native_optimiser_under_sanitizers(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout + run.stderr[-3000:]
     assert "rosenbrock" in run.stdout and "bowl5: ok" in run.stdout and "initial_params: ok" in run.stdout
+    assert "speculative rounds:" in run.stdout      # bitwise the plain trajectories, fewer rounds (checked inside)
 
 
 def test_julia_shim_file_matches_integration_md_and_the_header():
