@@ -1013,10 +1013,7 @@ static int enqueue_host_batch(gpcc_handle_t h, int M, const double *delays, cons
 static int ensure_lane(gpcc_handle_t h, int li, long M)
 {
     SmallLane &ln = h->lanes[li];
-    if (!ln.stream) {
-        if (li == 0) HIPCHK(h, hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
-        else HIPCHK(h, hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
-    }
+    if (!ln.stream) HIPCHK(h, hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
     if (M <= ln.cap) return 0;
     if (ln.par) hipHostFree(ln.par);
     if (ln.ll) hipHostFree(ln.ll);

@@ -38,6 +38,9 @@
 #define GPCC_SMALLW_MAXNB 24                     /* four waves per evaluation: N + 1 <= 384 */
 #define GPCC_SMALLW_MAXN (16 * GPCC_SMALLW_MAXNB - 1)
 #define GPCC_SMALL_DLD 17
+// blocks per staging pass of a row's elements (2 KiB each): half a row up to NB = 8, three blocks beyond -- NB = 9 and 10 then
+// stay within 20 KiB of LDS per wave, i.e. eight waves (two per SIMD) per CU
+#define GPCC_SMALL_SB(NB) ((NB) <= 8 ? ((NB) + 1) / 2 : ((NB) <= 10 ? 3 : ((NB) + 1) / 2))
 
 __device__ __forceinline__ void gpcc_small_potf2(const double *sD, double *sX, double *sr, const int lane, const bool last,
                                                  const int base, double &py, int &pe, int &bad, double &quad)
@@ -100,6 +103,9 @@ struct GpccSmallState {
 template <int KID, int NP>
 __device__ __forceinline__ void gpcc_small_block(const GpccSmallState &st, const int J, const int i, double (&val)[4])
 {
+    // no contraction across these statements: whether "(a a') k" and the "+ Sobs" / "+ B" that follow it fuse into an fma would
+    // otherwise be decided per instantiation, and the one-wave and four-wave kernels must return the same bits
+#pragma clang fp contract(off)
     const int lane = st.lane, lr = lane & 15, q = lane >> 4, N = st.N;
     const int gc = 16 * i + lr;
     const double uc = st.su[gc], ac = st.sa[gc];
@@ -139,7 +145,7 @@ __device__ __forceinline__ void gpcc_small_rows(d4 (&U)[NB][NB], GpccSmallState 
     if constexpr (J < NB) {
         typedef GpccPrec<double> PD;
         constexpr int NP = 16 * NB, DLD = GPCC_SMALL_DLD;
-        constexpr int SB = (NB + 1) / 2;   // blocks per staging pass (a row is assembled in at most two)
+        constexpr int SB = GPCC_SMALL_SB(NB);   // blocks per staging pass
         const int lane = st.lane, lr = lane & 15, q = lane >> 4;
         d4 T[NB];
         // ---- (a) row J of S = -(K bordered): blocks (J, i), i >= J, through the LDS stage
@@ -198,7 +204,7 @@ template <int NB, int KID, int WPE>
 __global__ __launch_bounds__(64, WPE) void gpcc_small_eval(GpccCtx c, GpccGroup g)
 {
     constexpr int NP = 16 * NB, DLD = GPCC_SMALL_DLD;
-    constexpr int SB = (NB + 1) / 2;
+    constexpr int SB = GPCC_SMALL_SB(NB);
     const int m = blockIdx.x;
     if (m >= g.cnt) return;
     const int lane = threadIdx.x & 63;

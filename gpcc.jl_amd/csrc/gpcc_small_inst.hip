@@ -10,7 +10,8 @@
 constexpr int KID = GPCC_INST_KID;
 
 #if !GPCC_INST_WIDE
-// one wave per evaluation: every block count 1 .. 12 (N <= 191); two waves per SIMD up to NB = 7, four up to NB = 3
+// one wave per evaluation: every block count 1 .. 12 (N <= 191); four waves per SIMD up to NB = 3, two up to NB = 10 (NB = 9, 10 with a
+// few dozen scratch accesses: measured 14.7 -> 20.0 M evaluations/s at N = 128, 12.3 -> 15.4 M/s at N = 150; NB = 11, 12: no gain), one beyond
 hipError_t GPCC_CAT(gpcc_small_launch_, GPCC_INST_KID)(int nb, const GpccCtx &c, const GpccGroup &g, hipStream_t s)
 {
     switch (nb) {
@@ -21,9 +22,9 @@ hipError_t GPCC_CAT(gpcc_small_launch_, GPCC_INST_KID)(int nb, const GpccCtx &c,
     case 5: gpcc_small_eval<5, KID, 2><<<g.cnt, 64, 0, s>>>(c, g); break;
     case 6: gpcc_small_eval<6, KID, 2><<<g.cnt, 64, 0, s>>>(c, g); break;
     case 7: gpcc_small_eval<7, KID, 2><<<g.cnt, 64, 0, s>>>(c, g); break;
-    case 8: gpcc_small_eval<8, KID, 1><<<g.cnt, 64, 0, s>>>(c, g); break;
-    case 9: gpcc_small_eval<9, KID, 1><<<g.cnt, 64, 0, s>>>(c, g); break;
-    case 10: gpcc_small_eval<10, KID, 1><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 8: gpcc_small_eval<8, KID, 2><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 9: gpcc_small_eval<9, KID, 2><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 10: gpcc_small_eval<10, KID, 2><<<g.cnt, 64, 0, s>>>(c, g); break;
     case 11: gpcc_small_eval<11, KID, 1><<<g.cnt, 64, 0, s>>>(c, g); break;
     default: gpcc_small_eval<12, KID, 1><<<g.cnt, 64, 0, s>>>(c, g); break;
     }

@@ -98,10 +98,11 @@ def test_four_waves_per_evaluation_sizes_192_to_383_and_small_batches(gp, oracle
         assert worst_o <= 1e-9 and worst_t <= 1e-11, (N, Nl, kname, mb, worst_o, worst_t)
     print("N = 192..383 (four waves per evaluation): worst vs oracle %.2e, vs tile kernels %.2e" % (worst_o, worst_t))
     worst = 0.0
-    for N in (64, 79, 110, 111, 112, 150, 159, 176, 191):
+    for N, kname in [(n, KNAMES[n % 4]) for n in (64, 79, 110, 111, 112, 150, 159, 176, 191)] + \
+                    [(16 * nb - 1 - (nb % 3), k) for nb in range(5, 13) for k in KNAMES]:   # every instantiation of both families
         t, y, s = _problem(rng, [N - N // 2, N // 2])
         delays, alpha, rho = _params(rng, 40, 2)
-        with gp.Objective(t, y, s, KNAMES[N % 4]) as obj:
+        with gp.Objective(t, y, s, kname) as obj:
             obj.set_option("small_wide_max", 0)          # one wave per evaluation
             a, ia = obj.loglik_batch(delays, alpha, rho)
             obj.set_option("small_wide_max", 256)        # four waves per evaluation for this batch of 40

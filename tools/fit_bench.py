@@ -10,6 +10,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
@@ -19,7 +20,14 @@ def main():
     ap.add_argument("--iterations", type=int, default=30)
     ap.add_argument("--restarts", type=int, default=1)
     ap.add_argument("--kernel", default="matern32")
-    args = ap.parse_args()
+    ap.add_argument("--readme", action="store_true",
+                    help="the reference's own documented sweeps instead (README.md:161, :195, :227: N = 110 / 150, 101 / 201 / 12321 "
+                         "delays, iterations = 1000) -- tools/readme_bench.py")
+    args, rest = ap.parse_known_args()
+    if args.readme:
+        import readme_bench
+        sys.argv = [sys.argv[0]] + rest
+        return readme_bench.main()
     import torch
 
     import gpcc_amd
