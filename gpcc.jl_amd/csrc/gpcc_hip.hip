@@ -306,7 +306,9 @@ extern "C" int gpcc_create(gpcc_handle_t *out, int L, const int *Nl, const doubl
     h->share_tiles = (L >= 2) ? Nl[0] / GPCC_TILE : 0;
     if (const char *e = getenv("GPCC_SMALL_N")) h->small_n = e[0] != '0';   // default of option "small_n" (A/B runs, tests of the tile kernels at small N)
     {   // default group size: 256 evaluations resident (one per CU in the diagonal step), capped at 64 GiB
-        const double per_slot = ((double)h->nt * (h->nt + 1) / 2 + (precision ? h->nt : 1)) * GPCC_TILE_ELEMS * (precision ? 4.0 : 8.0) + 16.0 * h->Np * (L + 1);
+        double per_slot = ((double)h->nt * (h->nt + 1) / 2 + (precision ? h->nt : 1)) * GPCC_TILE_ELEMS * (precision ? 4.0 : 8.0) + 16.0 * h->Np * (L + 1);
+        if (precision)   // fp32 mode: diag(K) as assembled, the refinement's per-tile partial sums, the pivot-ratio statistics
+            per_slot += 8.0 * h->Np + 8.0 * GPCC_MAXRHS * GPCC_MAXRHS * ((double)h->nt * (h->nt + 1) / 2) + 16.0;
         long cap = (long)(64.0 * 1024 * 1024 * 1024 / per_slot);
         if (cap < 8) cap = 8;
         if (h->slots_per_stream > cap) h->slots_per_stream = (int)(cap / 8 * 8);
@@ -470,7 +472,9 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "share_tiles")) return h->share_tiles;
     if (!strcmp(key, "N")) return h->N;
     if (!strcmp(key, "Np")) return h->Np;
-    if (!strcmp(key, "bytes_per_slot")) return (long)(((long)h->nt * (h->nt + 1) / 2 + (h->precision ? h->nt : 1)) * GPCC_TILE_ELEMS) * (h->precision ? 4 : 8) + 16L * h->Np * h->nrhs;
+    if (!strcmp(key, "bytes_per_slot"))
+        return (long)(((long)h->nt * (h->nt + 1) / 2 + (h->precision ? h->nt : 1)) * GPCC_TILE_ELEMS) * (h->precision ? 4 : 8) + 16L * h->Np * h->nrhs +
+               (h->precision ? 8L * h->Np + 8L * GPCC_MAXRHS * GPCC_MAXRHS * ((long)h->nt * (h->nt + 1) / 2) + 16L : 0L);
     if (!strcmp(key, "precision")) return h->precision;
     if (!strcmp(key, "fused_solve")) return h->fused_solve;
     if (!strcmp(key, "fused_solve_min")) return h->fused_solve_min;

@@ -50,6 +50,15 @@ while time.time() < t_end:
         with gp.Objective(t, y, s, kname, marginalise_b=mb, precision=prec, **opts) as obj:
             obj.set_option("right_looking_max", int(rng.choice([0, 8, 24, 64])))
             obj.set_option("fused_solve_min", int(rng.choice([1, 8, 112])))     # fused update/solve path also for small left-looking groups
+            # round 3: kernel family (tile kernels / one wave / four waves per evaluation), right-looking tail and its switch point,
+            # and the fit's device unpack / speculative rounds / host-thread slices
+            obj.set_option("small_n", int(rng.random() < 0.7))
+            obj.set_option("small_wide_max", int(rng.choice([0, 512, 10 ** 9])))
+            obj.set_option("hybrid_tail", int(rng.random() < 0.7))
+            obj.set_option("hybrid_mall_mb", int(rng.choice([20, 400, 4000])))
+            obj.set_option("fit_speculate", int(rng.random() < 0.5))
+            obj.set_option("fit_device_unpack", int(rng.random() < 0.5))
+            obj.set_option("fit_threads", int(rng.choice([0, 1, 3])))
             ll, info = obj.loglik_batch(delays, alpha, rho)
             ll2, info2 = obj.loglik_batch(delays, alpha, rho)
             assert np.array_equal(ll, ll2, equal_nan=True) and np.array_equal(info, info2), "not repeatable"
