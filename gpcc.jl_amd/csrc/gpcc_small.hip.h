@@ -28,7 +28,9 @@
 // -- the quadratic form of Distributions.logpdf -- and the forward substitution is the same MFMAs as the factorisation.
 // That pivot is skipped (set to 1), padding pivots are 1: sum log L_ii is unchanged.
 // (Round 3's first version kept the whole triangle in registers, right-looking, with dynamic block loops: 16.5 M evaluations/s
-// at N = 110 and 4.6 M/s with scratch spills at N = 150; this form: 30.4 and 11.4 M/s -- profiles/r03/.)
+// at N = 110 and 4.6 M/s with scratch spills at N = 150; this form: 30 and 15.4 M/s -- profiles/r03/.)
+// N = 192 ... 383 (and batches too small to fill the chip with one wave each) run FOUR waves per evaluation, block column i owned
+// by wave i % 4 -- gpcc_smallw_eval below; same arithmetic in the same order, so both forms return the same bits.
 #pragma once
 #include "gpcc_kernels.hip.h"
 #include "gpcc_transforms.h"
