@@ -126,6 +126,11 @@ struct gpcc_handle_s {
     int hybrid_mall_mb = 400;   // option "hybrid_mall_mb": budget for the trailing matrices of a group (256 MiB Infinity Cache; measured
                                 // best at 400: profiles/r03/midsize_tail_budget_sweep.log)
     int hybrid_occ = 384;       // option "hybrid_occ": ... and only steps with fewer left-looking jobs than this become right-looking
+    int split_min = 24;         // option "split_min": a group of at least this many evaluations (0 = never) runs as TWO halves on two
+                                // streams, so that the update of one half hides the diagonal-step / panel-solve chain of the other ...
+    int split_max = 240;        // option "split_max": ... up to this many (a fused-path group of 256 has no idle chain left to hide) ...
+    int split_nt_min = 16;      // option "split_nt_min": ... at N >= 128 * this (below, the halves only get in each other's way).
+                                // Measured: profiles/r03/midsize_split_groups.log (+3 ... +8 % for 24-111 evaluations at N >= 2048)
     int small_n = 1;         // option "small_n": N <= GPCC_SMALL_MAXN runs gpcc_small_eval (one launch per batch, one wave per evaluation,
                              // the matrix in registers; always fp64) instead of the tile kernels
     std::atomic<long> small_count{0};   // evaluations that took that path so far ("small_n_count")
@@ -144,6 +149,8 @@ struct gpcc_handle_s {
     long slot_stride = 0;
     hipStream_t str[GPCC_MAX_STREAMS] = {};
     hipEvent_t ev_done[GPCC_MAX_STREAMS] = {};
+    hipStream_t str2[GPCC_MAX_STREAMS] = {};      // second half of a split group (option "split_min")
+    hipEvent_t ev_fork[GPCC_MAX_STREAMS] = {}, ev_join[GPCC_MAX_STREAMS] = {};
     hipEvent_t ev_start = nullptr;
     hipStream_t main_stream = nullptr;
     // staging for the host-pointer API
@@ -377,6 +384,9 @@ static void free_workspace(gpcc_handle_t h)
     for (int s = 0; s < GPCC_MAX_STREAMS; ++s) {
         if (h->str[s]) { hipStreamDestroy(h->str[s]); h->str[s] = nullptr; }
         if (h->ev_done[s]) { hipEventDestroy(h->ev_done[s]); h->ev_done[s] = nullptr; }
+        if (h->str2[s]) { hipStreamDestroy(h->str2[s]); h->str2[s] = nullptr; }
+        if (h->ev_fork[s]) { hipEventDestroy(h->ev_fork[s]); h->ev_fork[s] = nullptr; }
+        if (h->ev_join[s]) { hipEventDestroy(h->ev_join[s]); h->ev_join[s] = nullptr; }
     }
     h->ws_ready = false;
 }
@@ -435,6 +445,13 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->hybrid_tail = v != 0;
     } else if (!strcmp(key, "hybrid_occ")) {
         h->hybrid_occ = (int)v;
+    } else if (!strcmp(key, "split_max")) {
+        h->split_max = (int)v;
+    } else if (!strcmp(key, "split_nt_min")) {
+        h->split_nt_min = (int)v;
+    } else if (!strcmp(key, "split_min")) {
+        if (v < 0) return fail(h, GPCC_ERR_ARGUMENT, "split_min must be >= 0");
+        h->split_min = (int)v;
     } else if (!strcmp(key, "hybrid_mall_mb")) {
         if (v < 0 || v > 4096) return fail(h, GPCC_ERR_ARGUMENT, "hybrid_mall_mb must be in [0,4096]");
         h->hybrid_mall_mb = (int)v;
@@ -481,6 +498,9 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "small_n")) return h->small_n;
     if (!strcmp(key, "hybrid_tail")) return h->hybrid_tail;
     if (!strcmp(key, "hybrid_mall_mb")) return h->hybrid_mall_mb;
+    if (!strcmp(key, "split_min")) return h->split_min;
+    if (!strcmp(key, "split_max")) return h->split_max;
+    if (!strcmp(key, "split_nt_min")) return h->split_nt_min;
     if (!strcmp(key, "fit_speculate")) return h->fit_speculate;
     if (!strcmp(key, "fit_device_unpack")) return h->fit_device_unpack;
     if (!strcmp(key, "fit_threads")) return h->fit_threads;
@@ -563,6 +583,9 @@ static int ensure_workspace(gpcc_handle_t h)
     for (int s = 0; s < h->streams; ++s) {
         HIPCHK(h, hipStreamCreateWithFlags(&h->str[s], hipStreamNonBlocking));
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_done[s], hipEventDisableTiming));
+        HIPCHK(h, hipStreamCreateWithFlags(&h->str2[s], hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork[s], hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[s], hipEventDisableTiming));
     }
     { int rc_ = set_kernel_attributes(h); if (rc_) return rc_; }
     h->ws_streams = h->streams;
@@ -618,15 +641,15 @@ static void launch_assemble(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &
     else { if (ext) launch_assemble_t<true, double>(c, g, s); else launch_assemble_t<false, double>(c, g, s); }
 }
 
-static int enqueue_factor(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s, bool f32);
+static int enqueue_factor(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s, bool f32, int concurrent);
 
 static int enqueue_group(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s, bool factor = true,
-                         bool ext = false, int f32 = -1)
+                         bool ext = false, int f32 = -1, int concurrent = 1)
 {
     const bool single = (f32 < 0) ? (h->precision == GPCC_PRECISION_FP32) : (f32 != 0);
     launch_assemble(h, c, g, s, ext, single);
     if (!factor) return 0;
-    int rc = enqueue_factor(h, c, g, s, single);
+    int rc = enqueue_factor(h, c, g, s, single, concurrent);
     if (rc || !single || !h->fp32_refine || !c.gpart || !c.linv_keep) return rc;
     {   // fp32: refine the quadratic forms in fp64 -- backward solve, X' K0 X on the fly, final arithmetic
         ProfScope pr(h, GPCC_PROF_REFINE, s);
@@ -646,7 +669,7 @@ static int enqueue_group(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, 
 }
 
 template <typename T>
-static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g_in, hipStream_t s)
+static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g_in, hipStream_t s, int concurrent)
 {
     // a handful of evaluations (one objective(alpha, rho), predictTest, postb): spread every evaluation's jobs over
     // the 8 XCDs; the usual mapping keeps an evaluation on the XCD blockIdx % 8 selects, 1/8 of the chip for one matrix
@@ -701,7 +724,7 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
     if (!right && !p && !g.spread && h->hybrid_tail && c.nt_fact == c.nt && c.nt >= 6) {
         const double tile_mb = GPCC_TILE_ELEMS * sizeof(T) / 1048576.0;
         int n = 0;
-        while ((double)g.cnt * (n + 1) * (n + 2) / 2 * tile_mb <= h->hybrid_mall_mb) ++n;   // trailing size the cache holds
+        while ((double)g.cnt * (n + 1) * (n + 2) / 2 * tile_mb * concurrent <= h->hybrid_mall_mb) ++n;   // trailing size the cache holds (shared by the halves of a split group)
         const int nocc = (h->hybrid_occ + g.cnt - 1) / g.cnt;                                // steps with fewer left-looking jobs than that
         if (n > nocc) n = nocc;
         if (n > c.nt - 1) n = c.nt - 1;                                                      // (right-looking from step 1 on)
@@ -742,10 +765,10 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
 }
 
 // left-looking blocked Cholesky + fused forward solve (+ Schur complement of non-factorised rows)
-static int enqueue_factor(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s, bool f32)
+static int enqueue_factor(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s, bool f32, int concurrent)
 {
-    if (f32) enqueue_factor_t<float>(h, c, g, s);
-    else enqueue_factor_t<double>(h, c, g, s);
+    if (f32) enqueue_factor_t<float>(h, c, g, s, concurrent);
+    else enqueue_factor_t<double>(h, c, g, s, concurrent);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, GPCC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return 0;
@@ -816,6 +839,24 @@ static int enqueue_batch(gpcc_handle_t h, int M, const double *d_delays, const d
         GpccCtx cg = c;
         if (h->share_now && h->share_tiles > 0 && h->share_tiles < h->nt && g.cnt > h->right_looking_max && g.cnt > 1)
             cg.share_p = h->share_tiles;
+        // a group of a few dozen evaluations spends up to a fifth of its time in the serial chain diagonal step -> panel solve
+        // with the chip nearly idle (16 evaluations at N = 4096: 2.1 of 8.9 ms): run it as two halves on two streams, so that
+        // the update of one half overlaps the chain of the other (same slots; each half picks its own path by its size)
+        const bool split = h->split_min > 0 && !h->prof && !cg.share_p && g.cnt >= h->split_min && g.cnt >= 2 &&
+                           g.cnt <= h->split_max && h->nt >= h->split_nt_min && h->nt > 1;
+        if (split) {
+            GpccGroup ga = g, gb = g;
+            ga.cnt = g.cnt >= 16 ? 8 * ((g.cnt + 15) / 16) : (g.cnt + 1) / 2;
+            gb.first = g.first + ga.cnt; gb.slot0 = g.slot0 + ga.cnt; gb.cnt = g.cnt - ga.cnt;
+            HIPCHK(h, hipEventRecord(h->ev_fork[s], h->str[s]));
+            HIPCHK(h, hipStreamWaitEvent(h->str2[s], h->ev_fork[s], 0));
+            rc = enqueue_group(h, cg, ga, h->str[s], true, false, -1, 2);
+            if (!rc) rc = enqueue_group(h, cg, gb, h->str2[s], true, false, -1, 2);
+            if (rc) return rc;
+            HIPCHK(h, hipEventRecord(h->ev_join[s], h->str2[s]));
+            HIPCHK(h, hipStreamWaitEvent(h->str[s], h->ev_join[s], 0));
+            continue;
+        }
         rc = enqueue_group(h, cg, g, h->str[s]);
         if (rc) return rc;
     }
@@ -1304,7 +1345,7 @@ extern "C" int gpcc_mvnormal_logpdf(int n, const double *Sigma, const double *mu
         memset(&g, 0, sizeof g);
         g.out_loglik = c.gram + GPCC_MAXRHS * GPCC_MAXRHS; g.out_info = d_info + 1; g.cnt = 1;
         gpcc_load_dense<double><<<nt * nt, 256>>>(c, 0, d_in, n, d_in + (size_t)n * n);
-        rc = enqueue_factor(&tmp, c, g, nullptr, false);
+        rc = enqueue_factor(&tmp, c, g, nullptr, false, 1);
         if (rc == 0) {
             e = hipMemcpy(loglik, g.out_loglik, sizeof(double), hipMemcpyDeviceToHost);
             if (e == hipSuccess) e = hipMemcpy(info, g.out_info, sizeof(int), hipMemcpyDeviceToHost);

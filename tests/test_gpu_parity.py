@@ -965,6 +965,38 @@ def test_fused_solve_path_agrees_with_three_kernel_path(gp, oracle, Nl, prec, to
         assert _rel(a[ok], ref[ok]) <= (LL_RTOL if prec == "fp64" else FP32_RTOL)
 
 
+@pytest.mark.parametrize("Nl,prec,M,cs", [([700, 650], "fp64", 37, 256), ([1024, 1030], "fp64", 75, 32), ([400, 380], "fp64", 130, 256),
+                                           ([900, 800], "fp32", 30, 256)])
+def test_split_groups_return_the_same_bits(gp, Nl, prec, M, cs):
+    """Option "split_min": a group runs as two halves on two streams (same slots, each half its own launches).  With the
+    size-dependent choices pinned (plain left-looking three-kernel path), every evaluation's arithmetic is the same, so the
+    results are bitwise those of the unsplit group -- odd sizes, a remainder group, an argument error and an fp32 handle
+    (refinement + guard) included; with the defaults back on, they agree to rounding."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves(Nl, seed=11)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    L = len(Nl)
+    rng = np.random.default_rng(2)
+    delays = np.concatenate([np.zeros((M, 1)), rng.random((M, L - 1)) * 12], 1)
+    alphas = np.tile(alpha, (M, 1)) * (0.7 + 0.6 * rng.random((M, L)))
+    rhos = np.full(M, rho) * (0.5 + rng.random(M))
+    alphas[M - 2, 0] = -1.0
+    with gp.Objective(t, y, s, gp.matern32, precision=prec, streams=2, slots_per_stream=cs) as obj:
+        for k, v in (("shared_prefix", 0), ("hybrid_tail", 0), ("right_looking_max", 0), ("fused_solve_min", 10 ** 6), ("split_min", 0)):
+            obj.set_option(k, v)
+        ref, rinfo = obj.loglik_batch(delays, alphas, rhos)
+        for k, v in (("split_min", 2), ("split_max", 10 ** 6), ("split_nt_min", 1)):
+            obj.set_option(k, v)
+        ll, info = obj.loglik_batch(delays, alphas, rhos)
+        assert np.array_equal(info, rinfo) and rinfo[M - 2] == -1 and (np.delete(rinfo, M - 2) == 0).all()
+        assert np.array_equal(ll, ref, equal_nan=True)
+        for k, v in (("hybrid_tail", 1), ("right_looking_max", 12), ("fused_solve_min", 112)):   # halves pick their paths by their own size
+            obj.set_option(k, v)
+        l2, i2 = obj.loglik_batch(delays, alphas, rhos)
+        ok = rinfo == 0
+        assert np.array_equal(i2, rinfo) and _rel(l2[ok], ref[ok]) <= (1e-11 if prec == "fp64" else 1e-5)
+
+
 @pytest.mark.parametrize("Nl,prec,M,tol", [([700, 650], "fp64", 20, 1e-11), ([1024, 1024], "fp64", 40, 1e-11), ([520, 500, 490], "fp64", 13, 1e-11),
                                             ([900, 800], "fp32", 30, 1e-5)])
 def test_right_looking_tail_agrees_with_plain_left_looking(gp, oracle, Nl, prec, M, tol):

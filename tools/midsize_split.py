@@ -14,7 +14,8 @@ from gpcc_amd import synthetic  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--sizes", default="2048,1024")
 ap.add_argument("--batches", default="16,24,32,48,64,96,128")
-ap.add_argument("--splits", default="1,2,3,4")
+ap.add_argument("--splits", default="1,2")
+ap.add_argument("--option", action="append", default=[], help="name=value, applied to every handle")
 args = ap.parse_args()
 for Nb in [int(x) for x in args.sizes.split(",")]:
     t, y, s, _ = synthetic.simulate_lightcurves([Nb, Nb], seed=1)
@@ -24,8 +25,14 @@ for Nb in [int(x) for x in args.sizes.split(",")]:
         line, ref = [], None
         for S in [int(x) for x in args.splits.split(",")]:
             cs = (M + S - 1) // S
-            with gpcc_amd.Objective(t, y, s, "matern32", streams=S, slots_per_stream=cs) as obj:
+            # S = 2: the library's own split (option "split_min": two halves on two streams, same slots); S > 2: S groups on S streams
+            with gpcc_amd.Objective(t, y, s, "matern32", streams=(S if S > 2 else 1), slots_per_stream=(cs if S > 2 else 256)) as obj:
                 obj.set_option("shared_prefix", 0)
+                obj.set_option("split_min", 2 if S == 2 else 0)
+                obj.set_option("split_nt_min", 1)
+                for kv in args.option:
+                    k, v = kv.split("=")
+                    obj.set_option(k, int(v))
                 ll, info = obj.loglik_batch(d, a, r)
                 assert (info == 0).all()
                 if ref is None:
