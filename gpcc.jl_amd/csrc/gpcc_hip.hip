@@ -128,9 +128,11 @@ struct gpcc_handle_s {
     int hybrid_occ = 384;       // option "hybrid_occ": ... and only steps with fewer left-looking jobs than this become right-looking
     int split_min = 24;         // option "split_min": a group of at least this many evaluations (0 = never) runs as TWO halves on two
                                 // streams, so that the update of one half hides the diagonal-step / panel-solve chain of the other ...
-    int split_max = 240;        // option "split_max": ... up to this many (a fused-path group of 256 has no idle chain left to hide) ...
-    int split_nt_min = 16;      // option "split_nt_min": ... at N >= 128 * this (below, the halves only get in each other's way).
+    int split_max = 160;        // option "split_max": ... up to this many (192: -1 ... -3 %; a fused-path group of 256 has no idle chain left to hide) ...
+    int split_nt_min = 12;      // option "split_nt_min": ... at N > 128 * (this - 1) (below, the halves only get in each other's way).
                                 // Measured: profiles/r03/midsize_split_groups.log (+3 ... +8 % for 24-111 evaluations at N >= 2048)
+    int split_small = 1;        // option "split_small": smaller groups too, where it was measured to pay (same log): 13-23 evaluations
+                                // up to N = 3072 (two right-looking halves: +5 ... +30 %), 6-12 evaluations from N = 2945 on (+5 ... +10 %)
     int small_n = 1;         // option "small_n": N <= GPCC_SMALL_MAXN runs gpcc_small_eval (one launch per batch, one wave per evaluation,
                              // the matrix in registers; always fp64) instead of the tile kernels
     std::atomic<long> small_count{0};   // evaluations that took that path so far ("small_n_count")
@@ -449,6 +451,8 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->split_max = (int)v;
     } else if (!strcmp(key, "split_nt_min")) {
         h->split_nt_min = (int)v;
+    } else if (!strcmp(key, "split_small")) {
+        h->split_small = v != 0;
     } else if (!strcmp(key, "split_min")) {
         if (v < 0) return fail(h, GPCC_ERR_ARGUMENT, "split_min must be >= 0");
         h->split_min = (int)v;
@@ -501,6 +505,7 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "split_min")) return h->split_min;
     if (!strcmp(key, "split_max")) return h->split_max;
     if (!strcmp(key, "split_nt_min")) return h->split_nt_min;
+    if (!strcmp(key, "split_small")) return h->split_small;
     if (!strcmp(key, "fit_speculate")) return h->fit_speculate;
     if (!strcmp(key, "fit_device_unpack")) return h->fit_device_unpack;
     if (!strcmp(key, "fit_threads")) return h->fit_threads;
@@ -842,8 +847,10 @@ static int enqueue_batch(gpcc_handle_t h, int M, const double *d_delays, const d
         // a group of a few dozen evaluations spends up to a fifth of its time in the serial chain diagonal step -> panel solve
         // with the chip nearly idle (16 evaluations at N = 4096: 2.1 of 8.9 ms): run it as two halves on two streams, so that
         // the update of one half overlaps the chain of the other (same slots; each half picks its own path by its size)
-        const bool split = h->split_min > 0 && !h->prof && !cg.share_p && g.cnt >= h->split_min && g.cnt >= 2 &&
-                           g.cnt <= h->split_max && h->nt >= h->split_nt_min && h->nt > 1;
+        bool split = h->split_min > 0 && g.cnt >= h->split_min && g.cnt <= h->split_max && h->nt >= h->split_nt_min;
+        if (h->split_min > 0 && h->split_small && g.cnt < h->split_min)
+            split = (g.cnt > GPCC_RIGHT_LOOKING_MAX && g.cnt < 24 && h->nt <= 24) || (g.cnt >= 6 && g.cnt <= GPCC_RIGHT_LOOKING_MAX && h->nt >= 24);
+        split = split && !h->prof && !cg.share_p && g.cnt >= 2 && h->nt > 1;
         if (split) {
             GpccGroup ga = g, gb = g;
             ga.cnt = g.cnt >= 16 ? 8 * ((g.cnt + 15) / 16) : (g.cnt + 1) / 2;

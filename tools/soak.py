@@ -59,6 +59,7 @@ while time.time() < t_end:
             obj.set_option("split_min", int(rng.choice([0, 2, 24])))            # groups as two halves on two streams
             obj.set_option("split_max", int(rng.choice([111, 240, 10 ** 6])))
             obj.set_option("split_nt_min", int(rng.choice([1, 16])))
+            obj.set_option("split_small", int(rng.random() < 0.5))
             obj.set_option("fit_speculate", int(rng.random() < 0.5))
             obj.set_option("fit_device_unpack", int(rng.random() < 0.5))
             obj.set_option("fit_threads", int(rng.choice([0, 1, 3])))
