@@ -114,7 +114,10 @@ struct gpcc_handle_s {
     std::vector<double> t_host, y_host, sig2_host;
     std::vector<int> band_host;
     // options
-    int streams = 1, slots_per_stream = 256, right_looking_max = GPCC_RIGHT_LOOKING_MAX;
+    int streams = 2;         // groups of a batch alternate between this many streams: the next group's assembly and first steps fill
+                             // the idle CUs of the previous group's last steps (headline +0.9 %, 4096 delays at N = 2048 +5 %:
+                             // profiles/r03/two_streams_ab.log); a batch of one group is unaffected
+    int slots_per_stream = 256, right_looking_max = GPCC_RIGHT_LOOKING_MAX;
     int fused_small_max = 12;  // groups of at most this many evaluations run gpcc_small_step (update + next diagonal step in one launch)
     int shared_prefix = 1;   // 0 off, 1 auto (host-pointer API detects it), 2 the caller asserts it
     int update_t = 0;        // diagnostic option "update_t": the three-kernel path with gpcc_update_solve<T, false> as its update (A/B of the transposed main loop)
@@ -942,6 +945,8 @@ static int fp32_guard_pass(gpcc_handle_t h, int M, const double *d_delays, const
     HIPCHK(h, hipMemcpyAsync(h->ll_host.data(), d_loglik, sizeof(double) * M, hipMemcpyDeviceToHost, caller));
     HIPCHK(h, hipMemcpyAsync(h->info_host.data(), d_info, sizeof(int) * M, hipMemcpyDeviceToHost, caller));
     HIPCHK(h, hipStreamSynchronize(caller));
+    for (int i = 0; i < M; ++i)   // a factorisation that broke down has no pivot ratios (the sums stop being meaningful at the failing pivot)
+        if (h->info_host[i] != 0) h->cond_host[2 * (size_t)i] = h->cond_host[2 * (size_t)i + 1] = INFINITY;
     if (!h->fp32_guard) return 0;
     h->fb_idx_host.clear();
     for (int i = 0; i < M; ++i)

@@ -83,7 +83,7 @@ int gpcc_multi_gathered(gpcc_handle_t handle, int which, long *blk_out, double *
  * call.  Any pointer may be NULL.  (One persistent host thread per device runs the shares; none is created per batch.) */
 int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms, double *total_ms);
 
-/* Tunables: "streams" (groups in flight on separate HIP streams, default 1), "slots_per_stream"
+/* Tunables: "streams" (groups in flight on separate HIP streams, default 2 since round 3), "slots_per_stream"
  * (evaluations resident per group, default 256 = one diagonal-block workgroup per CU, capped so
  * the workspace stays under 64 GiB), "right_looking_max" (groups of at most this many evaluations use
  * the right-looking update, default 12), "fused_small_max" (groups of at most this many evaluations, default 12, run the
@@ -124,7 +124,8 @@ int gpcc_get_constants(gpcc_handle_t handle, double *mean_b, double *Sigma_b, do
  * fp32 factorisation met a non-positive pivot, so that results stay within the 1e-3 bar of fp32 also for
  * ill-conditioned hyper-parameters (calibration: DESIGN.md 4.7).  Options: "fp32_guard" (1 default, 0 = never repeat),
  * "fp32_guard_count" (read-only: evaluations repeated so far).  The guard reads the estimates back, so an fp32
- * handle synchronises the caller's stream once per call (also in the _device form). */
+ * handle synchronises the caller's stream once per call (also in the _device form).  An evaluation whose fp32 factorisation
+ * broke down, or whose arguments were refused, reports +inf for both numbers. */
 int gpcc_get_conditioning(gpcc_handle_t handle, int M, double *out);
 
 /* THE HOT PATH.  objective(alpha, rho) of src/gpccfixdelay_marginaliseb.jl:133-141

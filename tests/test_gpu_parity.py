@@ -689,8 +689,9 @@ def test_hyperparameter_envelope(gp, oracle, sigma):
     assert 0 < repeated < M                       # both regimes occur in this batch
     if sigma < 0.5:
         assert rawerr > FP32_RTOL                 # without the guard fp32 (even refined) does not hold the bar here
-    unguarded = ok & (ratios <= 250.0) & (largest <= 4.0e3)   # evaluations that stayed in fp32 (mean AND largest pivot ratio
-                                                              # below the guard's limits) are bitwise the raw results
+    unguarded = ok & (rawinfo == 0) & (ratios <= 250.0) & (largest <= 4.0e3)   # evaluations that stayed in fp32 (factorised in fp32, mean AND
+                                                              # largest pivot ratio below the guard's limits) are bitwise the raw results
+    assert np.isinf(ratios[rawinfo > 0]).all()                # a broken-down fp32 factorisation reports no pivot ratios (and is repeated)
     assert np.array_equal(ll32[unguarded], raw[unguarded])
 
 
