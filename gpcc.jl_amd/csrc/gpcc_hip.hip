@@ -151,6 +151,9 @@ struct gpcc_handle_s {
     double *d_kdiag = nullptr, *d_cond = nullptr;   // fp32 mode: diag(K) as assembled, pivot-ratio sums (GpccCtx)
     double *d_gpart = nullptr;                      // fp32 mode: per-tile partials of X' K0 X (refinement)
     int fp32_refine = 1;                            // option "fp32_refine": 0 = no refinement of the quadratic forms
+    int fp32_assemble = 1;                          // option "fp32_assemble": fp32 tiles inside one band pair are EVALUATED in fp32 as well (0: in fp64,
+                                                    // rounded once).  +3.6 % at N = 4096; soak and adversarial search unchanged (worst 2.9e-5 / 3.4e-4):
+                                                    // profiles/r03/fp32_assembly_in_fp32.log
     long slot_stride = 0;
     hipStream_t str[GPCC_MAX_STREAMS] = {};
     hipEvent_t ev_done[GPCC_MAX_STREAMS] = {};
@@ -316,6 +319,7 @@ extern "C" int gpcc_create(gpcc_handle_t *out, int L, const int *Nl, const doubl
     h->woodbury = (precision == GPCC_PRECISION_FP32 && marginalise_b) ? 1 : 0;
     h->nrhs = h->woodbury ? L + 1 : 1;
     h->share_tiles = (L >= 2) ? Nl[0] / GPCC_TILE : 0;
+    if (const char *e = getenv("GPCC_FP32_ASSEMBLE")) h->fp32_assemble = e[0] != '0';   // default of option "fp32_assemble" (A/B runs of the accuracy tools)
     if (const char *e = getenv("GPCC_SMALL_N")) h->small_n = e[0] != '0';   // default of option "small_n" (A/B runs, tests of the tile kernels at small N)
     {   // default group size: 256 evaluations resident (one per CU in the diagonal step), capped at 64 GiB
         double per_slot = ((double)h->nt * (h->nt + 1) / 2 + (precision ? h->nt : 1)) * GPCC_TILE_ELEMS * (precision ? 4.0 : 8.0) + 16.0 * h->Np * (L + 1);
@@ -473,6 +477,8 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->fp32_guard = v != 0;
     } else if (!strcmp(key, "fp32_refine")) {
         h->fp32_refine = v != 0;
+    } else if (!strcmp(key, "fp32_assemble")) {
+        h->fp32_assemble = v != 0;
     } else if (!strcmp(key, "shared_prefix")) {
         if (v < 0 || v > 2) return fail(h, GPCC_ERR_ARGUMENT, "shared_prefix must be 0, 1 or 2");
         h->shared_prefix = (int)v;
@@ -518,6 +524,7 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "small_n_count")) return h->small_count;
     if (!strcmp(key, "fp32_guard")) return h->fp32_guard;
     if (!strcmp(key, "fp32_refine")) return h->fp32_refine;
+    if (!strcmp(key, "fp32_assemble")) return h->fp32_assemble;
     if (!strcmp(key, "fp32_guard_count")) return h->fb_count;
     return -1;
 }
@@ -615,6 +622,7 @@ static GpccCtx make_ctx(gpcc_handle_t h)
     c.L = h->L; c.N = h->N; c.Np = h->Np; c.nt = h->nt; c.kernel_id = h->kernel_id; c.marginalise_b = h->mb;
     c.nt_fact = h->nt;
     c.nrhs = h->nrhs; c.woodbury = h->woodbury; c.share_p = 0; c.store_l = 0;
+    c.asm32 = (h->precision == GPCC_PRECISION_FP32 && h->fp32_assemble && h->fp32_refine) ? 1 : 0;
     return c;
 }
 

@@ -87,6 +87,7 @@ struct GpccCtx {
     int share_p;   // > 0: the evaluations of a group share their first share_p tile rows (same band-1 alpha, rho, delay):
                    //      only the group's first slot (the leader) assembles / factorises them, the others read its tiles,
                    //      inv(L_kk) and W_k for k < share_p -- bitwise the same values they would have computed
+    int asm32;     // fp32 tiles: elements of tiles inside one band pair are EVALUATED in fp32 too (option "fp32_assemble")
     int store_l;   // gpcc_diag_factor also writes L_kk back (dense factor export); 0 on the log-likelihood path
     int woodbury;  // 1: the matrix is K0 = delayedCovariance + Sobs only; B = Q Sigma_b Q' enters through the
                    //    L x L capacitance matrix in fp64 (determinant lemma + Woodbury) -- the fp32 path
@@ -253,6 +254,27 @@ __device__ __forceinline__ double gpcc_kernel_eval(double xi, double xj, GpccKer
     }
 }
 
+// fp32 evaluation of the same kernels for fp32 tiles (option "fp32_assemble"): the distance r = |x_i - x_j| is formed in fp64
+// and rounded once, everything after it is fp32 (v_exp_f32 through __expf).  Relative error of an element ~ (3 + t) u32 with
+// t the exponent's magnitude, against u32 / 2 for "fp64, rounded once" -- irrelevant for the quadratic forms, which the
+// refinement pass recomputes from the exact fp64 elements, and a perturbation of the log-determinant of the same kind as (and
+// smaller than) the fp32 factorisation's own; the fp64 element costs ~30 double-rate VALU operations, this one 2 + ~9 fp32.
+template <int KID>
+__device__ __forceinline__ float gpcc_kernel_eval_f32(float r, float c1, float c2)
+{
+    if (KID == 0) {
+        return __expf(-(r * c1));
+    } else if (KID == 1) {
+        return __expf(-((0.5f * (r * r)) * c1));
+    } else if (KID == 2) {
+        const float t = (1.7320508f * r) * c1;
+        return (1.0f + t) * __expf(-t);
+    } else {
+        const float t = (2.2360680f * r) * c1;
+        return (1.0f + t + (5.0f * (r * r)) * c2) * __expf(-t);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // gpcc_assemble_tiles: K = delayedCovariance + Sobs (+ B) for `cnt` evaluations, written once,
 // lower-triangle tiles only, 16 B per lane fully coalesced (a workgroup store instruction
@@ -324,6 +346,27 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
     const int rb0 = sb[0][0], cb0 = sb[1][0];
     if (!diag_tile(I, J) && rb0 >= 0 && cb0 >= 0 && rb0 == sb[0][GPCC_TILE - 1] && cb0 == sb[1][GPCC_TILE - 1]) {
         const double bt = (c.marginalise_b != 0 && !c.woodbury && rb0 == cb0) ? ssb[rb0] : 0.0;
+        if (sizeof(T) == 4 && c.asm32 && bt == 0.0) {   // fp32 tiles, fp32 evaluation (see gpcc_kernel_eval_f32)
+            const float c1 = (float)kc.c1, c2 = (float)kc.c2;
+            const float acol = (float)sa[1][0];   // one band per side: one amplitude per side
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = (tid >> 3) + 32 * j;
+                const double ur = su[0][r];
+                const float amp = (float)sa[0][r] * acol;
+                const int cs = (sp ^ gpcc_sw(r)) * P::EP;
+#pragma unroll
+                for (int ch = 0; ch < P::NCH; ++ch) {
+                    const int col = ch * P::KC + cs;
+                    typename P::v16 v;
+#pragma unroll
+                    for (int h = 0; h < P::EP; ++h)
+                        v[h] = (T)(amp * gpcc_kernel_eval_f32<KID>((float)fabs(ur - su[1][col + h]), c1, c2));
+                    *(typename P::v16 *)(Tt + ch * (GPCC_TILE * P::KC) + r * P::KC + sp * P::EP) = v;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = (tid >> 3) + 32 * j;

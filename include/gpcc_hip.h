@@ -125,7 +125,9 @@ int gpcc_get_constants(gpcc_handle_t handle, double *mean_b, double *Sigma_b, do
  * ill-conditioned hyper-parameters (calibration: DESIGN.md 4.7).  Options: "fp32_guard" (1 default, 0 = never repeat),
  * "fp32_guard_count" (read-only: evaluations repeated so far).  The guard reads the estimates back, so an fp32
  * handle synchronises the caller's stream once per call (also in the _device form).  An evaluation whose fp32 factorisation
- * broke down, or whose arguments were refused, reports +inf for both numbers. */
+ * broke down, or whose arguments were refused, reports +inf for both numbers.  Option "fp32_assemble" (1 default): the elements of
+ * fp32 tiles that lie inside one band pair are evaluated in fp32 too (distance in fp64, rounded once; v_exp_f32) instead of in fp64
+ * and rounded once -- the quadratic forms are refined from the exact fp64 elements either way. */
 int gpcc_get_conditioning(gpcc_handle_t handle, int M, double *out);
 
 /* THE HOT PATH.  objective(alpha, rho) of src/gpccfixdelay_marginaliseb.jl:133-141

@@ -528,14 +528,20 @@ def test_fp32_medium_vs_oracle(gp, oracle, kname, mb):
     alphas = np.tile(alpha, (M, 1)) * (0.7 + 0.6 * rng.random((M, 2)))
     rhos = 2.0 + 3 * rng.random(M)
     ref, rinfo = oracle.loglik_batch(kname, t, y, s, delays, alphas, rhos, mb, nthreads=12)
-    with gp.Objective(t, y, s, kname, marginalise_b=mb, precision="fp32") as obj:
-        ll, info = obj.loglik_batch(delays, alphas, rhos)
     ok = rinfo == 0
     assert ok.sum() >= M // 2
-    assert (info[ok] == 0).all()
-    err = _rel(ll[ok], ref[ok])
-    print("fp32 %s mb=%s: max rel err %.3e" % (kname, mb, err))
-    assert err <= FP32_RTOL
+    res = {}
+    with gp.Objective(t, y, s, kname, marginalise_b=mb, precision="fp32") as obj:
+        for mode in (0, 1):   # elements of the fp32 tiles evaluated in fp64 and rounded once / evaluated in fp32 (option "fp32_assemble")
+            obj.set_option("fp32_assemble", mode)
+            ll, info = obj.loglik_batch(delays, alphas, rhos)
+            assert (info[ok] == 0).all()
+            res[mode] = ll
+            err = _rel(ll[ok], ref[ok])
+            print("fp32 %s mb=%s fp32_assemble=%d: max rel err %.3e" % (kname, mb, mode, err))
+            assert err <= FP32_RTOL
+    assert not np.array_equal(res[0][ok], res[1][ok])      # the option does select another assembly ...
+    assert _rel(res[1][ok], res[0][ok]) <= 1e-5            # ... whose results sit far inside the bar of the fp32 path
 
 
 def test_fp32_status_codes(gp, golden):

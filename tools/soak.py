@@ -60,6 +60,7 @@ while time.time() < t_end:
             obj.set_option("split_max", int(rng.choice([111, 240, 10 ** 6])))
             obj.set_option("split_nt_min", int(rng.choice([1, 16])))
             obj.set_option("split_small", int(rng.random() < 0.5))
+            obj.set_option("fp32_assemble", int(rng.random() < 0.6))            # fp32 tiles evaluated in fp32 / in fp64 and rounded once
             obj.set_option("fit_speculate", int(rng.random() < 0.5))
             obj.set_option("fit_device_unpack", int(rng.random() < 0.5))
             obj.set_option("fit_threads", int(rng.choice([0, 1, 3])))
