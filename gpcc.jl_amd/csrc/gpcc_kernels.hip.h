@@ -1822,14 +1822,30 @@ __global__ __launch_bounds__(256) void gpcc_refine_partials(GpccCtx c, GpccGroup
     // tiles inside one band pair and off the diagonal (most of them: points are ordered by band): no selects
     const bool plain = !diag && sb[0][0] >= 0 && sb[1][0] >= 0 && sb[0][0] == sb[0][GPCC_TILE - 1] && sb[1][0] == sb[1][GPCC_TILE - 1];
     if (plain) {
+        // one band per side: the amplitude product is one number per row (applied to the row sums), and the kernel's argument
+        // scale goes into the coordinates once per point instead of once per element: t = |u_i' - u_j'|, u' = u * kscale --
+        // 17 instead of 22 double-rate operations per element (the same element to ~2 ulp; the refinement needs K0 to ~1e-13)
+        const double kscale = (KID == 0) ? kc.c1 : (KID == 1) ? sqrt(0.5 * kc.c1) : (KID == 2) ? 1.7320508075688772 * kc.c1 : 2.23606797749979 * kc.c1;
+        const double us = ur * kscale;
+        __syncthreads();
+        if (tid < GPCC_TILE) su[1][tid] *= kscale;
+        __syncthreads();
 #pragma unroll 4
         for (int jj = 0; jj < 64; ++jj) {
             const int j = half * 64 + jj;
-            const double val = (ar * sa[1][j]) * gpcc_kernel_eval<KID>(ur, su[1][j], kc, sexp);
+            const double d = us - su[1][j];
+            double kv;
+            if (KID == 0) kv = gpcc_exp_nonpos_tab(-fabs(d), sexp);
+            else if (KID == 1) kv = gpcc_exp_nonpos_tab(-(d * d), sexp);
+            else if (KID == 2) kv = (1.0 + fabs(d)) * gpcc_exp_nonpos_tab(-fabs(d), sexp);
+            else kv = fma(fabs(d), fma(fabs(d), 1.0 / 3.0, 1.0), 1.0) * gpcc_exp_nonpos_tab(-fabs(d), sexp);
 #pragma unroll
             for (int a = 0; a < GPCC_MAXRHS; ++a)
-                if (a < nrhs) s[a] = fma(val, sx[1][a][j], s[a]);
+                if (a < nrhs) s[a] = fma(kv, sx[1][a][j], s[a]);
         }
+        const double amp = ar * sa[1][0];
+#pragma unroll
+        for (int a = 0; a < GPCC_MAXRHS; ++a) s[a] *= amp;
     } else {
 #pragma unroll 4
         for (int jj = 0; jj < 64; ++jj) {
