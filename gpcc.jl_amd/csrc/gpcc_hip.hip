@@ -135,7 +135,8 @@ struct gpcc_handle_s {
     int split_nt_min = 12;      // option "split_nt_min": ... at N > 128 * (this - 1) (below, the halves only get in each other's way).
                                 // Measured: profiles/r03/midsize_split_groups.log (+3 ... +8 % for 24-111 evaluations at N >= 2048)
     int split_small = 1;        // option "split_small": smaller groups too, where it was measured to pay (same log): 13-23 evaluations
-                                // up to N = 3072 (two right-looking halves: +5 ... +30 %), 6-12 evaluations from N = 2945 on (+5 ... +10 %)
+                                // up to N = 2048 and 13-19 up to N = 3072 (two right-looking halves: +5 ... +35 %), 6-12 evaluations
+                                // from N = 2945 on (+5 ... +10 %)
     int small_n = 1;         // option "small_n": N <= GPCC_SMALL_MAXN runs gpcc_small_eval (one launch per batch, one wave per evaluation,
                              // the matrix in registers; always fp64) instead of the tile kernels
     std::atomic<long> small_count{0};   // evaluations that took that path so far ("small_n_count")
@@ -860,11 +861,11 @@ static int enqueue_batch(gpcc_handle_t h, int M, const double *d_delays, const d
         // the update of one half overlaps the chain of the other (same slots; each half picks its own path by its size)
         bool split = h->split_min > 0 && g.cnt >= h->split_min && g.cnt <= h->split_max && h->nt >= h->split_nt_min;
         if (h->split_min > 0 && h->split_small && g.cnt < h->split_min)
-            split = (g.cnt > GPCC_RIGHT_LOOKING_MAX && g.cnt < 24 && h->nt <= 24) || (g.cnt >= 6 && g.cnt <= GPCC_RIGHT_LOOKING_MAX && h->nt >= 24);
+            split = (g.cnt > GPCC_RIGHT_LOOKING_MAX && g.cnt < 24 && (h->nt <= 16 || (h->nt <= 24 && g.cnt < 20))) || (g.cnt >= 6 && g.cnt <= GPCC_RIGHT_LOOKING_MAX && h->nt >= 24);
         split = split && !h->prof && !cg.share_p && g.cnt >= 2 && h->nt > 1;
         if (split) {
             GpccGroup ga = g, gb = g;
-            ga.cnt = g.cnt >= 16 ? 8 * ((g.cnt + 15) / 16) : (g.cnt + 1) / 2;
+            ga.cnt = g.cnt >= 24 ? 8 * ((g.cnt + 15) / 16) : (g.cnt + 1) / 2;   // (multiples of 8 keep an evaluation's workgroups on one XCD)
             gb.first = g.first + ga.cnt; gb.slot0 = g.slot0 + ga.cnt; gb.cnt = g.cnt - ga.cnt;
             HIPCHK(h, hipEventRecord(h->ev_fork[s], h->str[s]));
             HIPCHK(h, hipStreamWaitEvent(h->str2[s], h->ev_fork[s], 0));
