@@ -104,7 +104,7 @@ int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms
  * threads, 0 = by size -- none of the three changes a bit of the result).  "right_looking_max" now defaults to 12.
  * "split_min" / "split_max" / "split_nt_min" (24 / 160 / 12): a group of split_min ... split_max evaluations at N > 128 (split_nt_min - 1)
  * runs as two halves on two streams (the update of one half hides the diagonal-step / panel-solve chain of the other); split_min = 0:
- * never.  "split_small" (1): also 13-23 evaluations up to N = 3072 and 6-12 evaluations from N = 2945 on, where that was measured to pay.
+ * never.  "split_small" (1): also 13-23 evaluations up to N = 2048 (13-19 up to N = 3072) and 6-12 evaluations from N = 2945 on, where that was measured to pay.
  * gpcc_get_option also answers "N", "Np", "precision", "bytes_per_slot", "share_tiles", "n_devices", "gather_mode",
  * "small_n_max" (191), "small_n_active", "small_n_count". */
 int gpcc_set_option(gpcc_handle_t handle, const char *key, long value);
