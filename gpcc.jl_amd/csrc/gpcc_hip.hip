@@ -329,6 +329,9 @@ extern "C" int gpcc_create(gpcc_handle_t *out, int L, const int *Nl, const doubl
         long cap = (long)(64.0 * 1024 * 1024 * 1024 / per_slot);
         if (cap < 8) cap = 8;
         if (h->slots_per_stream > cap) h->slots_per_stream = (int)(cap / 8 * 8);
+        // the second stream doubles the workspace: only where both fit in half of the memory that is free now (N = 65536 does not)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || 2.0 * h->slots_per_stream * per_slot > 0.5 * (double)free_b) h->streams = 1;
     }
     std::vector<double> ht(h->Np, 0.0), hs(h->Np, 0.0), hr(h->Np, 0.0), hy(h->Np, 0.0);
     std::vector<int> hb(h->Np, -1);
@@ -969,6 +972,7 @@ static int fp32_guard_pass(gpcc_handle_t h, int M, const double *d_delays, const
                              GPCC_PRECISION_FP64, h->device);
         if (rc) return fail(h, rc, "fp32 guard: creating the fp64 handle failed: %s", g_err.c_str());
         gpcc_set_option(h->fb, "shared_prefix", 0);
+        gpcc_set_option(h->fb, "streams", 1);   // (its workspace is sized below for one stream's slots)
         h->fb_slots = 0;
     }
     {   // workspace of the fp64 repeat: as many slots as evaluations to repeat (a batch that is mostly ill-conditioned then
