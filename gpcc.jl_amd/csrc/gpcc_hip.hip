@@ -129,6 +129,9 @@ struct gpcc_handle_s {
     int hybrid_mall_mb = 400;   // option "hybrid_mall_mb": budget for the trailing matrices of a group (256 MiB Infinity Cache; measured
                                 // best at 400: profiles/r03/midsize_tail_budget_sweep.log)
     int hybrid_occ = 384;       // option "hybrid_occ": ... and only steps with fewer left-looking jobs than this become right-looking
+    int trsm_rows_jobs = 0;     // option "trsm_rows_jobs": three-kernel steps with at most this many panel-solve jobs use gpcc_panel_trsm_rows (quarter-
+                                // tile jobs on four times as many CUs).  Measured at 128: +1 ... +2.7 % for 13-64 evaluations at N = 2048, +0.4 % at
+                                // N = 4096 -- left OFF: the bits of an evaluation would then depend on the size of its group
     int split_min = 24;         // option "split_min": a group of at least this many evaluations (0 = never) runs as TWO halves on two
                                 // streams, so that the update of one half hides the diagonal-step / panel-solve chain of the other ...
     int split_max = 160;        // option "split_max": ... up to this many (192: -1 ... -3 %; a fused-path group of 256 has no idle chain left to hide) ...
@@ -458,6 +461,8 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->hybrid_tail = v != 0;
     } else if (!strcmp(key, "hybrid_occ")) {
         h->hybrid_occ = (int)v;
+    } else if (!strcmp(key, "trsm_rows_jobs")) {
+        h->trsm_rows_jobs = (int)v;
     } else if (!strcmp(key, "split_max")) {
         h->split_max = (int)v;
     } else if (!strcmp(key, "split_nt_min")) {
@@ -517,6 +522,7 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "hybrid_mall_mb")) return h->hybrid_mall_mb;
     if (!strcmp(key, "split_min")) return h->split_min;
     if (!strcmp(key, "split_max")) return h->split_max;
+    if (!strcmp(key, "trsm_rows_jobs")) return h->trsm_rows_jobs;
     if (!strcmp(key, "split_nt_min")) return h->split_nt_min;
     if (!strcmp(key, "split_small")) return h->split_small;
     if (!strcmp(key, "fit_speculate")) return h->fit_speculate;
@@ -770,7 +776,9 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
         if (k < c.nt - 1) {
             ProfScope pr(h, GPCC_PROF_TRSM, s);
             const int grid = (k < p) ? cnt8 * (c.nt - p) + (p - k - 1) : cnt8 * (c.nt - k - 1);
-            if (grid > 0) gpcc_panel_trsm<T><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
+            if (!p && g.cnt * (c.nt - k - 1) <= h->trsm_rows_jobs)   // few jobs: quarter-tile jobs on four times as many CUs
+                gpcc_panel_trsm_rows<T><<<g.cnt * (c.nt - k - 1) * 4, 512, GPCC_TRSM_ROWS_LDS_BYTES, s>>>(c, g, k);
+            else if (grid > 0) gpcc_panel_trsm<T><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
         }
         if (rstep && k < c.nt - 1) {
             ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
