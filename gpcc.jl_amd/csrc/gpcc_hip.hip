@@ -325,16 +325,18 @@ extern "C" int gpcc_create(gpcc_handle_t *out, int L, const int *Nl, const doubl
     h->share_tiles = (L >= 2) ? Nl[0] / GPCC_TILE : 0;
     if (const char *e = getenv("GPCC_FP32_ASSEMBLE")) h->fp32_assemble = e[0] != '0';   // default of option "fp32_assemble" (A/B runs of the accuracy tools)
     if (const char *e = getenv("GPCC_SMALL_N")) h->small_n = e[0] != '0';   // default of option "small_n" (A/B runs, tests of the tile kernels at small N)
-    {   // default group size: 256 evaluations resident (one per CU in the diagonal step), capped at 64 GiB
+    {   // default group size: 256 evaluations resident (one per CU in the diagonal step: cfg5, N = 16384 in fp32, 0.55 GB per slot, runs
+        // 88.1 evals/s with 256 slots against 84.8 with the 120 a 64 GiB cap allowed) wherever that fits 55 % of the memory free now
         double per_slot = ((double)h->nt * (h->nt + 1) / 2 + (precision ? h->nt : 1)) * GPCC_TILE_ELEMS * (precision ? 4.0 : 8.0) + 16.0 * h->Np * (L + 1);
         if (precision)   // fp32 mode: diag(K) as assembled, the refinement's per-tile partial sums, the pivot-ratio statistics
             per_slot += 8.0 * h->Np + 8.0 * GPCC_MAXRHS * GPCC_MAXRHS * ((double)h->nt * (h->nt + 1) / 2) + 16.0;
-        long cap = (long)(64.0 * 1024 * 1024 * 1024 / per_slot);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)64 << 30;
+        long cap = (long)(0.55 * (double)free_b / per_slot);
         if (cap < 8) cap = 8;
         if (h->slots_per_stream > cap) h->slots_per_stream = (int)(cap / 8 * 8);
-        // the second stream doubles the workspace: only where both fit in half of the memory that is free now (N = 65536 does not)
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || 2.0 * h->slots_per_stream * per_slot > 0.5 * (double)free_b) h->streams = 1;
+        // the second stream doubles the workspace: only where both fit in half of the memory that is free now
+        if (2.0 * h->slots_per_stream * per_slot > 0.5 * (double)free_b) h->streams = 1;
     }
     std::vector<double> ht(h->Np, 0.0), hs(h->Np, 0.0), hr(h->Np, 0.0), hy(h->Np, 0.0);
     std::vector<int> hb(h->Np, -1);
@@ -589,21 +591,32 @@ static int ensure_workspace(gpcc_handle_t h)
 {
     if (h->ws_ready && h->ws_streams == h->streams && h->ws_slots == h->slots_per_stream) return 0;
     HIPCHK(h, hipDeviceSynchronize());
-    free_workspace(h);
-    const long slots = (long)h->streams * h->slots_per_stream;
     h->slot_stride = ((long)h->nt * (h->nt + 1) / 2) * GPCC_TILE_ELEMS;
     const size_t esz = h->precision ? sizeof(float) : sizeof(double);
-    HIPCHK(h, hipMalloc(&h->d_tiles, esz * h->slot_stride * slots));
-    HIPCHK(h, hipMalloc(&h->d_linv, esz * GPCC_TILE_ELEMS * slots * (h->precision == GPCC_PRECISION_FP32 ? h->nt : 1)));
-    HIPCHK(h, hipMalloc(&h->d_z, sizeof(double) * h->Np * h->nrhs * slots));
-    HIPCHK(h, hipMalloc(&h->d_w, sizeof(double) * h->Np * h->nrhs * slots));
-    HIPCHK(h, hipMalloc(&h->d_logdet, sizeof(double) * slots));
-    HIPCHK(h, hipMalloc(&h->d_quad, sizeof(double) * GPCC_MAXRHS * GPCC_MAXRHS * slots));
-    HIPCHK(h, hipMalloc(&h->d_info, sizeof(int) * slots));
-    if (h->precision == GPCC_PRECISION_FP32) {
-        HIPCHK(h, hipMalloc(&h->d_kdiag, sizeof(double) * h->Np * slots));
-        HIPCHK(h, hipMalloc(&h->d_cond, sizeof(double) * 2 * slots));
-        HIPCHK(h, hipMalloc(&h->d_gpart, sizeof(double) * GPCC_MAXRHS * GPCC_MAXRHS * ((long)h->nt * (h->nt + 1) / 2) * slots));
+    for (;;) {
+        // The group size was chosen from the memory that was free when the handle was created; if somebody else (another handle,
+        // another process sharing the GPU) has taken it since, run smaller groups rather than fail: first one stream, then half the slots.
+        free_workspace(h);
+        const long slots = (long)h->streams * h->slots_per_stream;
+        hipError_t e = hipMalloc(&h->d_tiles, esz * h->slot_stride * slots);
+        if (e == hipSuccess) e = hipMalloc(&h->d_linv, esz * GPCC_TILE_ELEMS * slots * (h->precision == GPCC_PRECISION_FP32 ? h->nt : 1));
+        if (e == hipSuccess) e = hipMalloc(&h->d_z, sizeof(double) * h->Np * h->nrhs * slots);
+        if (e == hipSuccess) e = hipMalloc(&h->d_w, sizeof(double) * h->Np * h->nrhs * slots);
+        if (e == hipSuccess) e = hipMalloc(&h->d_logdet, sizeof(double) * slots);
+        if (e == hipSuccess) e = hipMalloc(&h->d_quad, sizeof(double) * GPCC_MAXRHS * GPCC_MAXRHS * slots);
+        if (e == hipSuccess) e = hipMalloc(&h->d_info, sizeof(int) * slots);
+        if (e == hipSuccess && h->precision == GPCC_PRECISION_FP32) {
+            e = hipMalloc(&h->d_kdiag, sizeof(double) * h->Np * slots);
+            if (e == hipSuccess) e = hipMalloc(&h->d_cond, sizeof(double) * 2 * slots);
+            if (e == hipSuccess) e = hipMalloc(&h->d_gpart, sizeof(double) * GPCC_MAXRHS * GPCC_MAXRHS * ((long)h->nt * (h->nt + 1) / 2) * slots);
+        }
+        if (e == hipSuccess) break;
+        (void)hipGetLastError();
+        free_workspace(h);
+        if (e != hipErrorOutOfMemory || (h->streams == 1 && h->slots_per_stream <= 1))
+            return fail(h, GPCC_ERR_HIP, "workspace of %ld slots: %s", slots, hipGetErrorString(e));
+        if (h->streams > 1) h->streams = 1;
+        else h->slots_per_stream = h->slots_per_stream > 16 ? (h->slots_per_stream / 2 + 7) / 8 * 8 : h->slots_per_stream / 2;
     }
     for (int s = 0; s < h->streams; ++s) {
         HIPCHK(h, hipStreamCreateWithFlags(&h->str[s], hipStreamNonBlocking));

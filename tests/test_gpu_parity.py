@@ -972,6 +972,39 @@ def test_fused_solve_path_agrees_with_three_kernel_path(gp, oracle, Nl, prec, to
         assert _rel(a[ok], ref[ok]) <= (LL_RTOL if prec == "fp64" else FP32_RTOL)
 
 
+def test_workspace_shrinks_when_the_memory_has_gone(gp):
+    """The group size is chosen from the memory that is free when the handle is created and the workspace is allocated on the first
+    batch; if another tenant of the GPU has taken the memory in between, the handle runs smaller groups (one stream, then half the
+    slots, ...) instead of failing -- same results."""
+    import torch
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([1024, 1024], seed=5)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    M = 40
+    delays = np.stack([np.zeros(M), np.linspace(0, 15, M)], 1)
+    alphas, rhos = np.tile(alpha, (M, 1)), np.full(M, rho)
+    with gp.Objective(t, y, s, gp.matern32) as obj:
+        for k, v in (("hybrid_tail", 0), ("split_min", 0)):      # (the bits of an evaluation then do not depend on its group)
+            obj.set_option(k, v)
+        ref, rinfo = obj.loglik_batch(delays, alphas, rhos)
+        want = obj.get_option("streams") * obj.get_option("slots_per_stream") * obj.get_option("bytes_per_slot")
+    assert (rinfo == 0).all() and want > 3 << 30
+    with gp.Objective(t, y, s, gp.matern32) as obj:              # created while the memory is free ...
+        for k, v in (("hybrid_tail", 0), ("split_min", 0)):
+            obj.set_option(k, v)
+        torch.cuda.init()
+        free_b, _ = torch.cuda.mem_get_info(0)
+        hog = torch.empty(free_b - (2 << 30), dtype=torch.uint8, device="cuda:0")   # ... then all but 2 GiB of it goes away
+        try:
+            ll, info = obj.loglik_batch(delays, alphas, rhos)
+            got = obj.get_option("streams") * obj.get_option("slots_per_stream") * obj.get_option("bytes_per_slot")
+        finally:
+            del hog
+            torch.cuda.empty_cache()
+    assert got <= want // 2                                      # (it did shrink: one stream and/or fewer slots)
+    assert np.array_equal(info, rinfo) and np.array_equal(ll, ref)
+
+
 @pytest.mark.parametrize("Nl,prec,M,cs", [([700, 650], "fp64", 37, 256), ([1024, 1030], "fp64", 75, 32), ([400, 380], "fp64", 130, 256),
                                            ([900, 800], "fp32", 30, 256)])
 def test_split_groups_return_the_same_bits(gp, Nl, prec, M, cs):
