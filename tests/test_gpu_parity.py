@@ -994,7 +994,10 @@ def test_workspace_shrinks_when_the_memory_has_gone(gp):
             obj.set_option(k, v)
         torch.cuda.init()
         free_b, _ = torch.cuda.mem_get_info(0)
-        hog = torch.empty(free_b - (2 << 30), dtype=torch.uint8, device="cuda:0")   # ... then all but 2 GiB of it goes away
+        try:
+            hog = torch.empty(free_b - (2 << 30), dtype=torch.uint8, device="cuda:0")   # ... then all but 2 GiB of it goes away
+        except RuntimeError as e:                                                       # (not this test's subject)
+            pytest.skip("could not occupy the GPU's memory: %s" % str(e)[:80])
         try:
             ll, info = obj.loglik_batch(delays, alphas, rhos)
             got = obj.get_option("streams") * obj.get_option("slots_per_stream") * obj.get_option("bytes_per_slot")
