@@ -105,6 +105,10 @@ int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms
  * "split_min" / "split_max" / "split_nt_min" (24 / 160 / 12): a group of split_min ... split_max evaluations at N > 128 (split_nt_min - 1)
  * runs as two halves on two streams (the update of one half hides the diagonal-step / panel-solve chain of the other); split_min = 0:
  * never.  "split_small" (1): also 13-23 evaluations up to N = 2048 (13-19 up to N = 3072) and 6-12 evaluations from N = 2945 on, where that was measured to pay.
+ * Diagnostic options (A/B measurements; defaults are the measured best): "hybrid_occ" (384: only steps with fewer left-looking jobs
+ * than this become right-looking), "small_wide_max" (512: batches of at most this many evaluations run four waves per evaluation
+ * on the small-N path), "trsm_rows_jobs" (0: three-kernel steps with at most this many panel-solve jobs use quarter-tile jobs),
+ * "update_t" (0: the three-kernel path with the fused kernel's transposed main loop as its update).
  * gpcc_get_option also answers "N", "Np", "precision", "bytes_per_slot", "share_tiles", "n_devices", "gather_mode",
  * "small_n_max" (191), "small_n_active", "small_n_count". */
 int gpcc_set_option(gpcc_handle_t handle, const char *key, long value);

@@ -103,3 +103,13 @@ def test_julia_shim_file_matches_integration_md_and_the_header():
     assert {"gpcc_create", "gpcc_destroy", "gpcc_loglik_batch", "gpcc_grid_loglik", "gpcc_probabilities", "gpcc_last_error"} <= syms
     for sym in syms:
         assert re.search(r"\b%s\(" % sym, header), sym
+
+
+def test_every_option_key_is_documented_in_the_header():
+    """Each key gpcc_set_option / gpcc_get_option accept is named in include/gpcc_hip.h."""
+    src = open(os.path.join(ROOT, "gpcc.jl_amd", "csrc", "gpcc_hip.hip")).read()
+    header = open(os.path.join(ROOT, "include", "gpcc_hip.h")).read()
+    keys = set(re.findall(r'!strcmp\(key, "([A-Za-z_0-9]+)"\)', src))
+    assert len(keys) >= 30
+    missing = sorted(k for k in keys if '"%s"' % k not in header)
+    assert not missing, missing
