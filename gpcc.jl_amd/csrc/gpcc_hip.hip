@@ -694,12 +694,20 @@ static int enqueue_group(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, 
         ProfScope pr(h, GPCC_PROF_REFINE, s);
         gpcc_back_solve<float><<<g.cnt, 512, 0, s>>>(c, g);
         dim3 grid(c.nt * c.nt, g.cnt);
+#define GPCC_REFINE_NR(KID)                                                                        \
+    switch (c.nrhs) {                                                                              \
+    case 1: gpcc_refine_partials<KID, 1><<<grid, 256, 0, s>>>(c, g); break;                        \
+    case 3: gpcc_refine_partials<KID, 3><<<grid, 256, 0, s>>>(c, g); break;                        \
+    case 4: gpcc_refine_partials<KID, 4><<<grid, 256, 0, s>>>(c, g); break;                        \
+    default: gpcc_refine_partials<KID, 0><<<grid, 256, 0, s>>>(c, g); break;                       \
+    }
         switch (c.kernel_id) {
-        case 0: gpcc_refine_partials<0><<<grid, 256, 0, s>>>(c, g); break;
-        case 1: gpcc_refine_partials<1><<<grid, 256, 0, s>>>(c, g); break;
-        case 2: gpcc_refine_partials<2><<<grid, 256, 0, s>>>(c, g); break;
-        default: gpcc_refine_partials<3><<<grid, 256, 0, s>>>(c, g); break;
+        case 0: GPCC_REFINE_NR(0) break;
+        case 1: GPCC_REFINE_NR(1) break;
+        case 2: GPCC_REFINE_NR(2) break;
+        default: GPCC_REFINE_NR(3) break;
         }
+#undef GPCC_REFINE_NR
         gpcc_refine_finish<<<g.cnt, 256, 0, s>>>(c, g);
     }
     hipError_t e = hipGetLastError();

@@ -1785,12 +1785,15 @@ __global__ __launch_bounds__(512) void gpcc_back_solve(GpccCtx c, GpccGroup g)
 // row sums s_a[i] = sum_j K_ij x_a[j] are needed:  off-diagonal tiles stand for (I,J) and (J,I):
 //     sum_ij K_ij (x_a[i] x_b[j] + x_a[j] x_b[i]) = sum_i (x_a[i] s_b[i] + x_b[i] s_a[i]).
 // Deterministic: fixed reduction tree, one partial per tile (no atomics).   grid (nt*nt, cnt), block 256.
-template <int KID>
+// NR: the number of right-hand sides at compile time (1: plain; 3, 4: woodbury with 2 / 3 bands), 0 = c.nrhs at run time --
+// with it the element loop is straight-line code (nine uniform branches per element otherwise).
+template <int KID, int NR>
 __global__ __launch_bounds__(256) void gpcc_refine_partials(GpccCtx c, GpccGroup g)
 {
     const int I = blockIdx.x / c.nt, J = blockIdx.x % c.nt;
     if (J > I) return;
-    const int m = blockIdx.y, slot = g.slot0 + m, tid = threadIdx.x, nrhs = c.nrhs;
+    const int m = blockIdx.y, slot = g.slot0 + m, tid = threadIdx.x, nrhs = NR ? NR : c.nrhs;
+    constexpr int NA = NR ? NR : GPCC_MAXRHS;
     if (c.info[slot] != 0 || gpcc_leader_failure(c, g) != 0) return;
     const double *delays = g.delays + (long)(g.first + m) * c.L;
     const double *alpha = g.alpha + (long)(g.first + m) * c.L;
@@ -1816,9 +1819,9 @@ __global__ __launch_bounds__(256) void gpcc_refine_partials(GpccCtx c, GpccGroup
     const bool diag = (I == J);
     const int br = sb[0][i];
     const double ur = su[0][i], ar = sa[0][i], sg = ssig[i];
-    double s[GPCC_MAXRHS];
+    double s[NA];
 #pragma unroll
-    for (int a = 0; a < GPCC_MAXRHS; ++a) s[a] = 0.0;
+    for (int a = 0; a < NA; ++a) s[a] = 0.0;
     // tiles inside one band pair and off the diagonal (most of them: points are ordered by band): no selects
     const bool plain = !diag && sb[0][0] >= 0 && sb[1][0] >= 0 && sb[0][0] == sb[0][GPCC_TILE - 1] && sb[1][0] == sb[1][GPCC_TILE - 1];
     if (plain) {
@@ -1835,12 +1838,12 @@ __global__ __launch_bounds__(256) void gpcc_refine_partials(GpccCtx c, GpccGroup
             if (KID == 2) kv *= 1.0 + t;
             else if (KID == 3) kv *= fma(t, fma(t, 1.0 / 3.0, 1.0), 1.0);
 #pragma unroll
-            for (int a = 0; a < GPCC_MAXRHS; ++a)
-                if (a < nrhs) s[a] = fma(kv, sx[1][a][j], s[a]);
+            for (int a = 0; a < NA; ++a)
+                if (NR || a < nrhs) s[a] = fma(kv, sx[1][a][j], s[a]);
         }
         const double amp = ar * sa[1][0];
 #pragma unroll
-        for (int a = 0; a < GPCC_MAXRHS; ++a) s[a] *= amp;
+        for (int a = 0; a < NA; ++a) s[a] *= amp;
     } else {
 #pragma unroll 4
         for (int jj = 0; jj < 64; ++jj) {
@@ -1850,8 +1853,8 @@ __global__ __launch_bounds__(256) void gpcc_refine_partials(GpccCtx c, GpccGroup
             if (diag && i == j) val = val + sg;
             if (br < 0 || bc < 0) val = 0.0;   // padding / explicit rows: X is zero there
 #pragma unroll
-            for (int a = 0; a < GPCC_MAXRHS; ++a)
-                if (a < nrhs) s[a] = fma(val, sx[1][a][j], s[a]);
+            for (int a = 0; a < NA; ++a)
+                if (NR || a < nrhs) s[a] = fma(val, sx[1][a][j], s[a]);
         }
     }
     // per-thread contribution to every (a,b), reduced over the 256 threads in a fixed order
