@@ -1747,15 +1747,26 @@ __global__ __launch_bounds__(512) void gpcc_back_solve(GpccCtx c, GpccGroup g)
                     }
                 }
                 __syncthreads();
+                if (na == RB) {   // the usual case (woodbury with two bands: 3 right-hand sides): straight-line code
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                    for (int u = 0; u < 8; ++u)
 #pragma unroll
-                    for (int a = 0; a < RB; ++a)
-                        if (a < na) {
+                        for (int a = 0; a < RB; ++a) {
                             const double xv = sx[a][rg + 16 * u];
 #pragma unroll
                             for (int h = 0; h < 4; ++h) acc[a][h] = fma((double)v[u][h], xv, acc[a][h]);
                         }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int a = 0; a < RB; ++a)
+                            if (a < na) {
+                                const double xv = sx[a][rg + 16 * u];
+#pragma unroll
+                                for (int h = 0; h < 4; ++h) acc[a][h] = fma((double)v[u][h], xv, acc[a][h]);
+                            }
+                }
             }
             __syncthreads();
 #pragma unroll
