@@ -9,6 +9,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
 
 
@@ -33,8 +34,11 @@ def counters(d, tag):
 
 def main():
     d = sys.argv[1]
+    # N / slots: the configuration the passes ran (bench.py's defaults) -- bench.py only quotes `traffic` from a summary that matches
     out = {"note": "PMC passes: one 256-evaluation group (bench.py --grid 256 --steps 1 --warmup 0); "
-                   "stats: default bench command", "kernels": {}}
+                   "stats: default bench command", "N": int(os.environ.get("GPCC_PMC_N", "4096")),
+           "slots": int(os.environ.get("GPCC_PMC_SLOTS", "256")), "source": "tools/profile_round.sh -> tools/pmc_summary.py %s" % d,
+           "kernels": {}}
     stats = glob.glob("%s/stats/*/*_kernel_stats.csv" % d)
     if stats:
         for r in csv.DictReader(open(stats[0])):
