@@ -367,10 +367,15 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
             }
             return;
         }
+        // one band per side: one amplitude per side, and the kernel's constants fold into ONE scale of the distance,
+        // t = |u_i - u_j| * kscale (the difference first: exact for nearby points) -- the same element as gpcc_kernel_eval's to an
+        // ulp or two (fewer roundings, not more), 3-6 operations and one LDS read cheaper
+        const double kscale = (KID == 0) ? kc.c1 : (KID == 1) ? 0.5 * kc.c1 : (KID == 2) ? 1.7320508075688772 * kc.c1 : 2.23606797749979 * kc.c1;
+        const double acol = sa[1][0];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = (tid >> 3) + 32 * j;
-            const double ur = su[0][r], ar = sa[0][r];
+            const double ur = su[0][r], amp = sa[0][r] * acol;
             const int cs = (sp ^ gpcc_sw(r)) * P::EP;
 #pragma unroll
             for (int ch = 0; ch < P::NCH; ++ch) {
@@ -378,8 +383,12 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
                 typename P::v16 v;
 #pragma unroll
                 for (int h = 0; h < P::EP; ++h) {
-                    const double kv = gpcc_kernel_eval<KID>(ur, su[1][col + h], kc);
-                    v[h] = (T)((ar * sa[1][col + h]) * kv + bt);   // same operations as the general path below
+                    const double d = ur - su[1][col + h];
+                    const double t = (KID == 1) ? (d * d) * kscale : fabs(d) * kscale;
+                    double kv = gpcc_exp_nonpos(-t);
+                    if (KID == 2) kv *= 1.0 + t;
+                    else if (KID == 3) kv *= fma(t, fma(t, 1.0 / 3.0, 1.0), 1.0);
+                    v[h] = (T)(amp * kv + bt);
                 }
                 *(typename P::v16 *)(Tt + ch * (GPCC_TILE * P::KC) + r * P::KC + sp * P::EP) = v;
             }
