@@ -275,6 +275,26 @@ __device__ __forceinline__ float gpcc_kernel_eval_f32(float r, float c1, float c
     }
 }
 
+// The same kernels with their constants folded into ONE scale of the distance (round 3): t = |x_i - x_j| * kscale (rbf:
+// (x_i - x_j)^2 * kscale), the difference first -- it is exact for nearby points -- then exp(-t) times the Matern polynomial
+// in t.  Fewer roundings than gpcc_kernel_eval and 1-4 operations cheaper; used by the select-free assembly path, the
+// refinement pass and the small-N kernels.
+template <int KID>
+__device__ __forceinline__ double gpcc_kernel_scale(GpccKernelConst kc)
+{
+    return (KID == 0) ? kc.c1 : (KID == 1) ? 0.5 * kc.c1 : (KID == 2) ? 1.7320508075688772 * kc.c1 : 2.23606797749979 * kc.c1;
+}
+template <int KID>
+__device__ __forceinline__ double gpcc_kernel_eval_scaled(double xi, double xj, double kscale)
+{
+    const double d = xi - xj;
+    const double t = (KID == 1) ? (d * d) * kscale : fabs(d) * kscale;
+    double kv = gpcc_exp_nonpos(-t);
+    if (KID == 2) kv = kv * (1.0 + t);
+    else if (KID == 3) kv = kv * fma(t, fma(t, 1.0 / 3.0, 1.0), 1.0);
+    return kv;
+}
+
 // ------------------------------------------------------------------------------------------
 // gpcc_assemble_tiles: K = delayedCovariance + Sobs (+ B) for `cnt` evaluations, written once,
 // lower-triangle tiles only, 16 B per lane fully coalesced (a workgroup store instruction
@@ -370,7 +390,7 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
         // one band per side: one amplitude per side, and the kernel's constants fold into ONE scale of the distance,
         // t = |u_i - u_j| * kscale (the difference first: exact for nearby points) -- the same element as gpcc_kernel_eval's to an
         // ulp or two (fewer roundings, not more), 3-6 operations and one LDS read cheaper
-        const double kscale = (KID == 0) ? kc.c1 : (KID == 1) ? 0.5 * kc.c1 : (KID == 2) ? 1.7320508075688772 * kc.c1 : 2.23606797749979 * kc.c1;
+        const double kscale = gpcc_kernel_scale<KID>(kc);
         const double acol = sa[1][0];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -383,12 +403,7 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
                 typename P::v16 v;
 #pragma unroll
                 for (int h = 0; h < P::EP; ++h) {
-                    const double d = ur - su[1][col + h];
-                    const double t = (KID == 1) ? (d * d) * kscale : fabs(d) * kscale;
-                    double kv = gpcc_exp_nonpos(-t);
-                    if (KID == 2) kv *= 1.0 + t;
-                    else if (KID == 3) kv *= fma(t, fma(t, 1.0 / 3.0, 1.0), 1.0);
-                    v[h] = (T)(amp * kv + bt);
+                    v[h] = (T)(amp * gpcc_kernel_eval_scaled<KID>(ur, su[1][col + h], kscale) + bt);
                 }
                 *(typename P::v16 *)(Tt + ch * (GPCC_TILE * P::KC) + r * P::KC + sp * P::EP) = v;
             }

@@ -96,6 +96,7 @@ struct GpccSmallState {
     double *sstage, *sD, *sX, *sr;
     const double *sig2, *resid;
     GpccKernelConst kc;
+    double kscale;   // gpcc_kernel_scale<KID>(kc)
     int N, lane;
     double py, quad;   // prod of the mantissas of 1 / sqrt(d_j); r' K^-1 r
     int pe, bad;       // sum of their exponents; order of the first non-positive pivot
@@ -118,7 +119,7 @@ __device__ __forceinline__ void gpcc_small_block(const GpccSmallState &st, const
     for (int r = 0; r < 4; ++r) {
         const int gr = 16 * J + q + 4 * r;
         br[r] = st.sbd[gr];
-        const double kv = gpcc_kernel_eval<KID>(st.su[gr], uc, st.kc);   // kernel(x - delays[i], y - delays[j]; rho)
+        const double kv = gpcc_kernel_eval_scaled<KID>(st.su[gr], uc, st.kscale);   // kernel(x - delays[i], y - delays[j]; rho)
         val[r] = (st.sa[gr] * ac) * kv;                                  // scale[i] scale[j] kernel, delayedCovariance.jl:27
     }
     if (i == J) {   // (wave-uniform) + Sobs, marginaliseb.jl:89, :135; padding: 1, right-hand-side row: 0
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(64, WPE) void gpcc_small_eval(GpccCtx c, GpccGroup 
 
     GpccSmallState st;
     st.su = su; st.sa = sa; st.ssb = ssb; st.sbd = sbd; st.sstage = sstage; st.sD = sD; st.sX = sX; st.sr = sr;
-    st.sig2 = c.sig2; st.resid = c.resid; st.kc = gpcc_kernel_const<KID>(rho); st.N = N; st.lane = lane;
+    st.sig2 = c.sig2; st.resid = c.resid; st.kc = gpcc_kernel_const<KID>(rho); st.kscale = gpcc_kernel_scale<KID>(st.kc); st.N = N; st.lane = lane;
     st.py = 1.0; st.quad = 0.0; st.pe = 0; st.bad = 0;
     d4 U[NB][NB];   // finished rows: U[m][i], i > m
     gpcc_small_rows<NB, KID, 0>(U, st);
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(64 * W, WGS) void gpcc_smallw_eval(GpccCtx c, GpccG
 
     GpccSmallState st;
     st.su = su; st.sa = sa; st.ssb = ssb; st.sbd = sbd; st.sstage = sstage; st.sD = sD; st.sX = sX; st.sr = sr;
-    st.sig2 = c.sig2; st.resid = c.resid; st.kc = gpcc_kernel_const<KID>(rho); st.N = N; st.lane = lane;
+    st.sig2 = c.sig2; st.resid = c.resid; st.kc = gpcc_kernel_const<KID>(rho); st.kscale = gpcc_kernel_scale<KID>(st.kc); st.N = N; st.lane = lane;
     st.py = 1.0; st.quad = 0.0; st.pe = 0; st.bad = 0;
     d4 U[NB][NC];
     gpcc_smallw_rows<NB, KID, W, 0>(U, st, scol, sred, sflag, w);
