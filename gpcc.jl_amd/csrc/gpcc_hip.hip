@@ -124,6 +124,10 @@ struct gpcc_handle_s {
     int fused_solve_min = 112;   // ... from this group size on (below it the diagonal tile's serial K-loop on ONE CU per evaluation costs
                                  // more than the fused solve saves: measured crossover 96-128 evaluations at N = 1024 and N = 4096)
     int fused_solve = 1;     // option "fused_solve": left-looking groups run gpcc_syrk_diag + gpcc_update_solve (2 launches per step)
+    int step_fused = 0;      // option "step_fused": ... as ONE launch per step (gpcc_step: the diagonal step of column k+1 inside the update
+                             // launch of column k, on half a CU's LDS); 0 = the two launches of round 2
+    int diag_blocks = 0;     // option "diag_blocks": the three-kernel path's diagonal step on the packed block image (gpcc_diag_factor2,
+                             // 80 KiB of LDS: two workgroups per CU, or one beside an update workgroup); 0 = gpcc_diag_factor (158.7 KiB)
     int hybrid_tail = 1;     // option "hybrid_tail": left-looking groups of the three-kernel path finish RIGHT-looking once their
                              // trailing matrices fit the Infinity Cache and the left-looking steps would leave CUs idle
     int hybrid_mall_mb = 400;   // option "hybrid_mall_mb": budget for the trailing matrices of a group (256 MiB Infinity Cache; measured
@@ -453,6 +457,10 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->update_t = (int)v;
     } else if (!strcmp(key, "fused_solve")) {
         h->fused_solve = v != 0;
+    } else if (!strcmp(key, "step_fused")) {
+        h->step_fused = v != 0;
+    } else if (!strcmp(key, "diag_blocks")) {
+        h->diag_blocks = v != 0;
     } else if (!strcmp(key, "fused_solve_min")) {
         h->fused_solve_min = (int)v;
     } else if (!strcmp(key, "small_n")) {
@@ -514,11 +522,13 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "N")) return h->N;
     if (!strcmp(key, "Np")) return h->Np;
     if (!strcmp(key, "bytes_per_slot"))
-        return (long)(((long)h->nt * (h->nt + 1) / 2 + (h->precision ? h->nt : 1)) * GPCC_TILE_ELEMS) * (h->precision ? 4 : 8) + 16L * h->Np * h->nrhs +
+        return (long)(((long)h->nt * (h->nt + 1) / 2 + (h->precision ? h->nt : 2)) * GPCC_TILE_ELEMS) * (h->precision ? 4 : 8) + 16L * h->Np * h->nrhs +
                (h->precision ? 8L * h->Np + 8L * GPCC_MAXRHS * GPCC_MAXRHS * ((long)h->nt * (h->nt + 1) / 2) + 16L : 0L);
     if (!strcmp(key, "precision")) return h->precision;
     if (!strcmp(key, "fused_solve")) return h->fused_solve;
     if (!strcmp(key, "fused_solve_min")) return h->fused_solve_min;
+    if (!strcmp(key, "step_fused")) return h->step_fused;
+    if (!strcmp(key, "diag_blocks")) return h->diag_blocks;
     if (!strcmp(key, "small_n")) return h->small_n;
     if (!strcmp(key, "hybrid_tail")) return h->hybrid_tail;
     if (!strcmp(key, "hybrid_mall_mb")) return h->hybrid_mall_mb;
@@ -576,6 +586,10 @@ static int set_kernel_attributes(gpcc_handle_t h)
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_update_solve<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_update_solve<double, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_update_solve<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_step<double>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_step<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_diag_factor2<double>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_DB_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_diag_factor2<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_DB_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<double, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
@@ -599,7 +613,7 @@ static int ensure_workspace(gpcc_handle_t h)
         free_workspace(h);
         const long slots = (long)h->streams * h->slots_per_stream;
         hipError_t e = hipMalloc(&h->d_tiles, esz * h->slot_stride * slots);
-        if (e == hipSuccess) e = hipMalloc(&h->d_linv, esz * GPCC_TILE_ELEMS * slots * (h->precision == GPCC_PRECISION_FP32 ? h->nt : 1));
+        if (e == hipSuccess) e = hipMalloc(&h->d_linv, esz * GPCC_TILE_ELEMS * slots * (h->precision == GPCC_PRECISION_FP32 ? h->nt : 2));
         if (e == hipSuccess) e = hipMalloc(&h->d_z, sizeof(double) * h->Np * h->nrhs * slots);
         if (e == hipSuccess) e = hipMalloc(&h->d_w, sizeof(double) * h->Np * h->nrhs * slots);
         if (e == hipSuccess) e = hipMalloc(&h->d_logdet, sizeof(double) * slots);
@@ -638,7 +652,7 @@ static GpccCtx make_ctx(gpcc_handle_t h)
     c.tiles = h->d_tiles; c.linv = h->d_linv; c.z = h->d_z; c.w = h->d_w;
     c.logdet = h->d_logdet; c.gram = h->d_quad; c.info = h->d_info;
     c.kdiag = h->d_kdiag; c.cond = h->d_cond; c.gpart = h->d_gpart;
-    c.linv_keep = (h->precision == GPCC_PRECISION_FP32) ? 1 : 0;
+    c.linv_keep = (h->precision == GPCC_PRECISION_FP32) ? 1 : 2;
     c.t = h->d_t; c.sig2 = h->d_sig2; c.resid = h->d_resid; c.band = h->d_band; c.yv = h->d_yv;
     for (int l = 0; l < GPCC_MAXL; ++l) c.sigma_b[l] = (l < h->L) ? h->sigma_b[l] : 0.0;
     c.slot_stride = h->slot_stride;
@@ -689,7 +703,7 @@ static int enqueue_group(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, 
     launch_assemble(h, c, g, s, ext, single);
     if (!factor) return 0;
     int rc = enqueue_factor(h, c, g, s, single, concurrent);
-    if (rc || !single || !h->fp32_refine || !c.gpart || !c.linv_keep) return rc;
+    if (rc || !single || !h->fp32_refine || !c.gpart || c.linv_keep != 1) return rc;
     {   // fp32: refine the quadratic forms in fp64 -- backward solve, X' K0 X on the fly, final arithmetic
         ProfScope pr(h, GPCC_PROF_REFINE, s);
         gpcc_back_solve<float><<<g.cnt, 512, 0, s>>>(c, g);
@@ -747,6 +761,15 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
     if (!right && !p && c.nt_fact == c.nt && h->fused_solve && g.cnt >= h->fused_solve_min && !c.store_l) {
         // left-looking, the panel solve inside the update (gpcc_update_solve): per step the diagonal tile first
         // (gpcc_syrk_diag: lower-triangle update + diagonal step in one workgroup per evaluation), then the rest of column k
+        if (h->step_fused && c.nrhs <= GPCC_DB_MAXRHS) {
+            // ONE launch per step: the workgroup that owns tile (k+1,k) goes on into the diagonal step of column k+1 (look-ahead,
+            // gpcc_step) while the rest of the launch takes the tiles below; launch -1 is the diagonal step of column 0
+            for (int k = -1; k < c.nt - 1; ++k) {
+                ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
+                gpcc_step<T><<<cnt8 * (k < 0 ? 1 : c.nt - k - 1), GPCC_GEMM_THREADS, GPCC_UPSOLVE_LDS_BYTES, s>>>(c, g, k);
+            }
+            return;
+        }
         for (int k = 0; k < c.nt; ++k) {
             {
                 ProfScope pr(h, GPCC_PROF_DIAG, s);
@@ -792,7 +815,8 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
         }
         {
             ProfScope pr(h, GPCC_PROF_DIAG, s);
-            gpcc_diag_factor<T><<<(k < p) ? 1 : g.cnt, GPCC_DIAG_THREADS, GPCC_DIAG_LDS_BYTES, s>>>(c, g, k);
+            if (h->diag_blocks && c.nrhs <= GPCC_DB_MAXRHS) gpcc_diag_factor2<T><<<(k < p) ? 1 : g.cnt, GPCC_DIAG_THREADS, GPCC_DB_LDS_BYTES, s>>>(c, g, k);
+            else gpcc_diag_factor<T><<<(k < p) ? 1 : g.cnt, GPCC_DIAG_THREADS, GPCC_DIAG_LDS_BYTES, s>>>(c, g, k);
         }
         if (k < c.nt - 1) {
             ProfScope pr(h, GPCC_PROF_TRSM, s);

@@ -91,13 +91,20 @@ int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms
  * "fused_solve" (1 = default: left-looking groups run the panel solve inside the update kernel and the diagonal tile's update
  * inside the diagonal step -- two launches per step; 0 = the three-kernel path of round 1; results agree to ~1e-13),
  * "fused_solve_min" (default 112: groups smaller than this keep the three-kernel path, which is faster there),
+ * "step_fused" (round 4; 0 = default; 1: those two launches are ONE -- gpcc_step: the workgroup that owns tile (k+1,k) goes on into the
+ * diagonal step of column k+1 while the rest of the launch updates column k, LAPACK's look-ahead; results bitwise those of
+ * step_fused = 0), "diag_blocks" (round 4; 0 = default; 1: the diagonal step of the three-kernel path keeps the tile as 36 packed
+ * 16 x 16 blocks and inverts in place -- 80 KiB of LDS instead of a whole CU's 158.7 KiB, bitwise the same results; both need at
+ * most 4 right-hand sides, i.e. fp32 handles with more than 3 bands keep the round-2 kernels).  Both were built to let the
+ * diagonal step run beside update workgroups and MEASURED not to pay (the fp64 matrix pipe bounds the step, and the pivot chain
+ * runs 2-3x slower beside MFMA-saturating waves than alone on a CU: DESIGN.md 4.2e), hence off,
  * "shared_prefix" (0 off; 1 = default: gpcc_loglik_batch detects a
  * batch whose evaluations all have the same band-1 amplitude, delay and rho -- a fixed-hyper-parameter delay
  * sweep, README.md:172-174 -- and then factorises the tile rows wholly inside band 1 once per group instead of
  * once per evaluation, results bitwise identical; 2 = the caller asserts that property, also for the _device
- * form).  Round 3: "small_n" (1 = default: N <= 191 -- the sizes of the reference's documentation, README.md:156-287 -- runs
- * the small-N family: ONE launch per batch, one wave per evaluation, the matrix in registers, always fp64 whatever the handle's
- * precision; 0 = the tile kernels; environment GPCC_SMALL_N sets the default), "hybrid_tail" (1 = default: left-looking groups of
+ * form).  Round 3: "small_n" (1 = default: N <= 383 -- the sizes of the reference's documentation, README.md:156-287, and a bit
+ * beyond -- runs the small-N family: ONE launch per batch, one wave (N <= 191) or four waves per evaluation, the matrix in registers,
+ * always fp64: the precision of an fp32 handle is IGNORED for N <= 383 (faster and more accurate there); 0 = the tile kernels; environment GPCC_SMALL_N sets the default), "hybrid_tail" (1 = default: left-looking groups of
  * 13-111 evaluations finish right-looking once their trailing matrices fit "hybrid_mall_mb" = 400 MB), "fit_device_unpack" /
  * "fit_speculate" / "fit_threads" (gpcc_grid_loglik on the small-N path: the kernel unpacks the optimiser's vectors itself;
  * latency-bound rounds evaluate all four candidate points of an iteration at once; large grids run as up to 4 slices on host
@@ -110,14 +117,14 @@ int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms
  * on the small-N path), "trsm_rows_jobs" (0: three-kernel steps with at most this many panel-solve jobs use quarter-tile jobs),
  * "update_t" (0: the three-kernel path with the fused kernel's transposed main loop as its update).
  * gpcc_get_option also answers "N", "Np", "precision", "bytes_per_slot", "share_tiles", "n_devices", "gather_mode",
- * "small_n_max" (191), "small_n_active", "small_n_count". */
+ * "small_n_max" (383), "small_n_active", "small_n_count". */
 int gpcc_set_option(gpcc_handle_t handle, const char *key, long value);
 long gpcc_get_option(gpcc_handle_t handle, const char *key);
 
 /* mu_b[L], Sigma_b[L], resid[N] as precomputed at create (any pointer may be NULL). */
 int gpcc_get_constants(gpcc_handle_t handle, double *mean_b, double *Sigma_b, double *resid);
 
-/* fp32 handles (N >= 192; smaller problems are evaluated in fp64 by the small-N kernels and report zeros here):
+/* fp32 handles (N >= 384; smaller problems are evaluated in fp64 by the small-N kernels and report zeros here):
  * [sum_i K_ii / d_i, max_i K_ii / d_i] over the Cholesky pivots d_i of each of the first M evaluations
  * of the last gpcc_loglik_batch / gpcc_loglik_batch_device call (2 M doubles) -- the conditioning measure behind the
  * fp32 accuracy guard.  An fp32 handle (a) refines the quadratic forms r'K^-1 r, Q'K^-1 Q, Q'K^-1 r in fp64 after the
@@ -239,7 +246,7 @@ enum {
     GPCC_PROF_TRSM = 3,         /* gpcc_panel_trsm         -- fp64 MFMA */
     GPCC_PROF_REFINE = 4,       /* fp32 mode: backward solve + X' K0 X + final arithmetic */
     GPCC_PROF_SMALL_STEP = 5,   /* gpcc_small_step: trailing update + next diagonal step in one launch (a few evaluations) */
-    GPCC_PROF_SMALL_EVAL = 6,   /* gpcc_small_eval: a whole evaluation (assembly + Cholesky + solve) of N <= 191 points in one wave */
+    GPCC_PROF_SMALL_EVAL = 6,   /* gpcc_small_eval / gpcc_smallw_eval: a whole evaluation (assembly + Cholesky + solve) of N <= 383 points in one or four waves */
     GPCC_PROF_COUNT = 7
 };
 int gpcc_profile_enable(gpcc_handle_t handle, int on);
