@@ -210,13 +210,18 @@ class Objective:
         return out
 
     def gathered(self, which=0):
-        """Multi-device handles: the all-gathered [loglik | info] blocks of the last loglik_batch as they sit on
-        device `which` -> (loglik[n_devices, blk], info[n_devices, blk]) (padding: NaN / 0)."""
+        """Multi-device handles: what the ONE all-gather of the last call left on device `which`.
+        After loglik_batch: (loglik[n_devices, blk], info[n_devices, blk]) (padding: NaN / 0).
+        After grid_loglik (the fit, sharded by delay): rows[n_devices, blk, L + 4] = [loglik, info, iterations, rho, alpha(L)] per
+        fitted delay; device i's row j is delay j * n_devices + i of the grid (round-robin deal)."""
         blk = ctypes.c_long(0)
         self._chk(_capi.load().gpcc_multi_gathered(self._h, int(which), ctypes.byref(blk), None, 0))
         n = self.get_option("n_devices")
-        buf = np.empty(2 * blk.value * n, dtype=np.float64)
+        w = self.get_option("gather_width")
+        buf = np.empty(w * blk.value * n, dtype=np.float64)
         self._chk(_capi.load().gpcc_multi_gathered(self._h, int(which), ctypes.byref(blk), _dp(buf), buf.size))
+        if w != 2:
+            return buf.reshape(n, blk.value, w)
         buf = buf.reshape(n, 2, blk.value)
         return buf[:, 0, :], buf[:, 1, :].astype(np.int32)
 

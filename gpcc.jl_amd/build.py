@@ -36,6 +36,7 @@ def build(force=False, verbose=False):
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
     flags = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed", "-c"]
+    flags += os.environ.get("GPCC_BUILD_DEFINES", "").split()     # A/B builds (tools/ab_exp.sh: -DGPCC_AB_POLY_EXP into GPCC_HIP_LIB)
     objdir = tempfile.mkdtemp(prefix="gpcc_build_")
     jobs = [(os.path.join(objdir, "gpcc_hip.o"), [os.path.join(CSRC, "gpcc_hip.hip")])]
     for wide in (1, 0):
@@ -45,21 +46,28 @@ def build(force=False, verbose=False):
 
     def compile_one(job):
         obj, args = job
-        return subprocess.run(flags + args + ["-o", obj], capture_output=True, text=True)
+        cmd = flags + args + ["-o", obj]
+        return cmd, subprocess.run(cmd, capture_output=True, text=True)
 
     workers = max(1, min(len(jobs), int(os.environ.get("GPCC_BUILD_JOBS", "0")) or (os.cpu_count() or 4)))
     with ThreadPoolExecutor(workers) as pool:
         results = list(pool.map(compile_one, jobs))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + [j[0] for j in jobs] + ["-L" + libdir, "-lrccl", "-pthread"]
-    res = next((r for r in results if r.returncode), None) or subprocess.run(cmd, capture_output=True, text=True)
+    failed = [(c, r) for c, r in results if r.returncode]
+    if not failed:
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + [j[0] for j in jobs] + ["-L" + libdir, "-lrccl", "-pthread"]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode:
+            failed = [(cmd, res)]
+        elif verbose:
+            print(" ".join(cmd))
+            print(res.stdout, res.stderr)
     shutil.rmtree(objdir, ignore_errors=True)
-    if verbose or res.returncode:
-        print(" ".join(cmd))
-        print(res.stdout, res.stderr)
-    if res.returncode:
+    if failed:      # every failing command with ITS diagnostics (not the link line with one compile's stderr)
         if os.path.exists(tmp):
             os.remove(tmp)
-        raise RuntimeError("hipcc failed:\n" + res.stderr)
+        report = "\n".join("$ %s\n%s%s" % (" ".join(c), r.stdout, r.stderr) for c, r in failed)
+        print(report)
+        raise RuntimeError("hipcc failed (%d command%s):\n%s" % (len(failed), "" if len(failed) == 1 else "s", report))
     os.replace(tmp, LIB_PATH)
     return LIB_PATH
 

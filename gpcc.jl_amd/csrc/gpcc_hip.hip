@@ -152,7 +152,8 @@ struct gpcc_handle_s {
     bool share_now = false;  // decision for the batch being enqueued
     // workspace
     bool ws_ready = false;
-    int ws_streams = 0, ws_slots = 0;
+    int ws_streams = 0, ws_slots = 0;           // what the workspace holds (smaller than the options if the memory was short)
+    int ws_req_streams = 0, ws_req_slots = 0;   // the option values it was built for
     double *d_tiles = nullptr, *d_linv = nullptr, *d_z = nullptr, *d_w = nullptr, *d_logdet = nullptr,
            *d_quad = nullptr;   // d_quad: Gram matrices (slots x MAXRHS^2)
     int *d_info = nullptr;
@@ -209,8 +210,9 @@ struct gpcc_handle_s {
     std::vector<hipEvent_t> ev_a, ev_b;   // per sub: around its share of the last batch (statistics)
     std::vector<double> stat_compute_ms;  // per device: its share of the last batch, on its stream (HIP events)
     double stat_gather_ms = 0.0, stat_total_ms = 0.0;   // the all-gather + final copies, and the whole call, host wall clock
-    long gather_cap = 0;                  // evaluations per device the gather buffers hold
-    long gather_blk = 0;                  // block length of the last gathered batch
+    long gather_cap = 0;                  // doubles per device the gather buffers hold
+    long gather_blk = 0;                  // block length of the last gathered batch / fit ...
+    int gather_width = 2;                 // ... and doubles per evaluation in it (2: [loglik | info]; L + 4: a fitted delay)
     int gather_mode = 0;                  // GPCC_GATHER_*
     bool is_multi() const { return !subs.empty(); }
 };
@@ -280,6 +282,9 @@ struct DeviceGuard {
     if (guard_.rc) return guard_.rc
 
 static int multi_destroy(gpcc_handle_t h);
+static int multi_grid_loglik(gpcc_handle_t h, int G, const double *delays, int iterations, int R, int C, double rhomin, double rhomax,
+                            const double *cands, double *loglik_out, double *alpha_out, double *rho_out, int *info_out,
+                            int *iterations_out, long long *stats_out);
 static int multi_loglik_batch(gpcc_handle_t h, int M, const double *delays, const double *alpha, const double *rho,
                               double *loglik, int *info);
 
@@ -330,17 +335,20 @@ extern "C" int gpcc_create(gpcc_handle_t *out, int L, const int *Nl, const doubl
     if (const char *e = getenv("GPCC_FP32_ASSEMBLE")) h->fp32_assemble = e[0] != '0';   // default of option "fp32_assemble" (A/B runs of the accuracy tools)
     if (const char *e = getenv("GPCC_SMALL_N")) h->small_n = e[0] != '0';   // default of option "small_n" (A/B runs, tests of the tile kernels at small N)
     {   // default group size: 256 evaluations resident (one per CU in the diagonal step: cfg5, N = 16384 in fp32, 0.55 GB per slot, runs
-        // 88.1 evals/s with 256 slots against 84.8 with the 120 a 64 GiB cap allowed) wherever that fits 55 % of the memory free now
-        double per_slot = ((double)h->nt * (h->nt + 1) / 2 + (precision ? h->nt : 1)) * GPCC_TILE_ELEMS * (precision ? 4.0 : 8.0) + 16.0 * h->Np * (L + 1);
+        // 88.1 evals/s with 256 slots against 84.8 with the 120 a 64 GiB cap allowed) wherever that fits 55 % of the device's TOTAL
+        // memory -- not of what happens to be free: the group size selects the factorisation path, so the same handle must dispatch the
+        // same way on every run whatever else occupies the GPU (if the memory is not there when the workspace is allocated, the
+        // workspace shrinks and says so: ensure_workspace)
+        double per_slot = ((double)h->nt * (h->nt + 1) / 2 + (precision ? h->nt : 2)) * GPCC_TILE_ELEMS * (precision ? 4.0 : 8.0) + 16.0 * h->Np * (L + 1);
         if (precision)   // fp32 mode: diag(K) as assembled, the refinement's per-tile partial sums, the pivot-ratio statistics
             per_slot += 8.0 * h->Np + 8.0 * GPCC_MAXRHS * GPCC_MAXRHS * ((double)h->nt * (h->nt + 1) / 2) + 16.0;
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)64 << 30;
-        long cap = (long)(0.55 * (double)free_b / per_slot);
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) total_b = (size_t)64 << 30;
+        long cap = (long)(0.55 * (double)total_b / per_slot);
         if (cap < 8) cap = 8;
         if (h->slots_per_stream > cap) h->slots_per_stream = (int)(cap / 8 * 8);
-        // the second stream doubles the workspace: only where both fit in half of the memory that is free now
-        if (2.0 * h->slots_per_stream * per_slot > 0.5 * (double)free_b) h->streams = 1;
+        // the second stream doubles the workspace: only where both fit in half of the memory
+        if (2.0 * h->slots_per_stream * per_slot > 0.5 * (double)total_b) h->streams = 1;
     }
     std::vector<double> ht(h->Np, 0.0), hs(h->Np, 0.0), hr(h->Np, 0.0), hy(h->Np, 0.0);
     std::vector<int> hb(h->Np, -1);
@@ -512,9 +520,12 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!h || !key) return -1;
     if (!strcmp(key, "n_devices")) return h->is_multi() ? (long)h->subs.size() : 1;
     if (!strcmp(key, "gather_mode")) return h->gather_mode;
+    if (!strcmp(key, "gather_width")) return h->gather_width;
     h = primary(h);
     if (!strcmp(key, "streams")) return h->streams;
     if (!strcmp(key, "slots_per_stream")) return h->slots_per_stream;
+    if (!strcmp(key, "workspace_streams")) return h->ws_ready ? h->ws_streams : h->streams;       // (differ from the options only if the
+    if (!strcmp(key, "workspace_slots")) return h->ws_ready ? h->ws_slots : h->slots_per_stream;  //  memory was short at allocation)
     if (!strcmp(key, "right_looking_max")) return h->right_looking_max;
     if (!strcmp(key, "fused_small_max")) return h->fused_small_max;
     if (!strcmp(key, "shared_prefix")) return h->shared_prefix;
@@ -603,15 +614,17 @@ static int set_kernel_attributes(gpcc_handle_t h)
 // ------------------------------------------------------------------------------------------
 static int ensure_workspace(gpcc_handle_t h)
 {
-    if (h->ws_ready && h->ws_streams == h->streams && h->ws_slots == h->slots_per_stream) return 0;
+    if (h->ws_ready && h->ws_req_streams == h->streams && h->ws_req_slots == h->slots_per_stream) return 0;
     HIPCHK(h, hipDeviceSynchronize());
     h->slot_stride = ((long)h->nt * (h->nt + 1) / 2) * GPCC_TILE_ELEMS;
     const size_t esz = h->precision ? sizeof(float) : sizeof(double);
+    int run_streams = h->streams, run_slots = h->slots_per_stream;   // what the workspace really gets: the OPTIONS stay what the caller set
     for (;;) {
-        // The group size was chosen from the memory that was free when the handle was created; if somebody else (another handle,
-        // another process sharing the GPU) has taken it since, run smaller groups rather than fail: first one stream, then half the slots.
+        // The group size was chosen from the device's memory; if somebody else (another handle, another process sharing the GPU) holds
+        // it, run smaller groups rather than fail: first one stream, then half the slots.  Reported, not silent: "workspace_streams" /
+        // "workspace_slots" say what is in use and gpcc_last_error carries a note.
         free_workspace(h);
-        const long slots = (long)h->streams * h->slots_per_stream;
+        const long slots = (long)run_streams * run_slots;
         hipError_t e = hipMalloc(&h->d_tiles, esz * h->slot_stride * slots);
         if (e == hipSuccess) e = hipMalloc(&h->d_linv, esz * GPCC_TILE_ELEMS * slots * (h->precision == GPCC_PRECISION_FP32 ? h->nt : 2));
         if (e == hipSuccess) e = hipMalloc(&h->d_z, sizeof(double) * h->Np * h->nrhs * slots);
@@ -627,12 +640,12 @@ static int ensure_workspace(gpcc_handle_t h)
         if (e == hipSuccess) break;
         (void)hipGetLastError();
         free_workspace(h);
-        if (e != hipErrorOutOfMemory || (h->streams == 1 && h->slots_per_stream <= 1))
+        if (e != hipErrorOutOfMemory || (run_streams == 1 && run_slots <= 1))
             return fail(h, GPCC_ERR_HIP, "workspace of %ld slots: %s", slots, hipGetErrorString(e));
-        if (h->streams > 1) h->streams = 1;
-        else h->slots_per_stream = h->slots_per_stream > 16 ? (h->slots_per_stream / 2 + 7) / 8 * 8 : h->slots_per_stream / 2;
+        if (run_streams > 1) run_streams = 1;
+        else run_slots = run_slots > 16 ? (run_slots / 2 + 7) / 8 * 8 : run_slots / 2;
     }
-    for (int s = 0; s < h->streams; ++s) {
+    for (int s = 0; s < run_streams; ++s) {
         HIPCHK(h, hipStreamCreateWithFlags(&h->str[s], hipStreamNonBlocking));
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_done[s], hipEventDisableTiming));
         HIPCHK(h, hipStreamCreateWithFlags(&h->str2[s], hipStreamNonBlocking));
@@ -640,9 +653,17 @@ static int ensure_workspace(gpcc_handle_t h)
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[s], hipEventDisableTiming));
     }
     { int rc_ = set_kernel_attributes(h); if (rc_) return rc_; }
-    h->ws_streams = h->streams;
-    h->ws_slots = h->slots_per_stream;
+    h->ws_streams = run_streams;
+    h->ws_slots = run_slots;
+    h->ws_req_streams = h->streams;
+    h->ws_req_slots = h->slots_per_stream;
     h->ws_ready = true;
+    if (run_streams != h->streams || run_slots != h->slots_per_stream) {   // a note, not an error: the call goes on with smaller groups
+        char buf[256];
+        snprintf(buf, sizeof buf, "note: the device's memory did not hold %d x %d slots; the workspace runs %d x %d (options unchanged)",
+                 h->streams, h->slots_per_stream, run_streams, run_slots);
+        h->err = buf;
+    }
     return 0;
 }
 
@@ -894,8 +915,8 @@ static int enqueue_batch(gpcc_handle_t h, int M, const double *d_delays, const d
     if (rc) return rc;
     if (!h->share_now) h->share_now = (h->shared_prefix == 2);   // device pointers cannot be inspected: only on assertion
     const GpccCtx c = make_ctx(h);
-    const int S = h->prof ? 1 : h->streams;  // profiling serialises groups onto one stream
-    const int cs = h->slots_per_stream;
+    const int S = h->prof ? 1 : h->ws_streams;  // profiling serialises groups onto one stream
+    const int cs = h->ws_slots;
     const int ngroups = (M + cs - 1) / cs;
     const int used = ngroups < S ? ngroups : S;
     HIPCHK(h, hipEventRecord(h->ev_start, caller));
@@ -917,23 +938,39 @@ static int enqueue_batch(gpcc_handle_t h, int M, const double *d_delays, const d
         // the update of one half overlaps the chain of the other (same slots; each half picks its own path by its size)
         bool split = h->split_min > 0 && g.cnt >= h->split_min && g.cnt <= h->split_max && h->nt >= h->split_nt_min;
         if (h->split_min > 0 && h->split_small && g.cnt < h->split_min)
-            split = (g.cnt > GPCC_RIGHT_LOOKING_MAX && g.cnt < 24 && (h->nt <= 16 || (h->nt <= 24 && g.cnt < 20))) || (g.cnt >= 6 && g.cnt <= GPCC_RIGHT_LOOKING_MAX && h->nt >= 24);
+            split = (g.cnt > h->right_looking_max && g.cnt < 24 && (h->nt <= 16 || (h->nt <= 24 && g.cnt < 20))) || (g.cnt >= 6 && g.cnt <= h->right_looking_max && h->nt >= 24);
         split = split && !h->prof && !cg.share_p && g.cnt >= 2 && h->nt > 1;
         if (split) {
             GpccGroup ga = g, gb = g;
             ga.cnt = g.cnt >= 24 ? 8 * ((g.cnt + 15) / 16) : (g.cnt + 1) / 2;   // (multiples of 8 keep an evaluation's workgroups on one XCD)
             gb.first = g.first + ga.cnt; gb.slot0 = g.slot0 + ga.cnt; gb.cnt = g.cnt - ga.cnt;
-            HIPCHK(h, hipEventRecord(h->ev_fork[s], h->str[s]));
-            HIPCHK(h, hipStreamWaitEvent(h->str2[s], h->ev_fork[s], 0));
-            rc = enqueue_group(h, cg, ga, h->str[s], true, false, -1, 2);
-            if (!rc) rc = enqueue_group(h, cg, gb, h->str2[s], true, false, -1, 2);
-            if (rc) return rc;
-            HIPCHK(h, hipEventRecord(h->ev_join[s], h->str2[s]));
-            HIPCHK(h, hipStreamWaitEvent(h->str[s], h->ev_join[s], 0));
+            hipError_t he = hipEventRecord(h->ev_fork[s], h->str[s]);
+            if (he == hipSuccess) he = hipStreamWaitEvent(h->str2[s], h->ev_fork[s], 0);
+            if (he == hipSuccess) {
+                rc = enqueue_group(h, cg, ga, h->str[s], true, false, -1, 2);
+                if (!rc) rc = enqueue_group(h, cg, gb, h->str2[s], true, false, -1, 2);
+            }
+            if (he == hipSuccess && !rc) he = hipEventRecord(h->ev_join[s], h->str2[s]);
+            if (he == hipSuccess && !rc) he = hipStreamWaitEvent(h->str[s], h->ev_join[s], 0);
+            if (he != hipSuccess && !rc) rc = fail(h, GPCC_ERR_HIP, "split group: %s", hipGetErrorString(he));
+            if (rc) break;
             continue;
         }
         rc = enqueue_group(h, cg, g, h->str[s]);
-        if (rc) return rc;
+        if (rc) break;
+    }
+    if (rc) {
+        // whatever was enqueued (possibly one half of a split group on its own stream, never joined) still reads the caller's
+        // parameter arrays and writes its outputs: nothing may be left running when the error is returned
+        const std::string msg = h->err;
+        for (int s = 0; s < h->ws_streams; ++s) {
+            if (h->str[s]) (void)hipStreamSynchronize(h->str[s]);
+            if (h->str2[s]) (void)hipStreamSynchronize(h->str2[s]);
+        }
+        (void)hipGetLastError();
+        h->err = msg;
+        h->share_now = false;
+        return rc;
     }
     for (int s = 0; s < used; ++s) {
         HIPCHK(h, hipEventRecord(h->ev_done[s], h->str[s]));
@@ -1656,8 +1693,13 @@ extern "C" int gpcc_grid_loglik(gpcc_handle_t h, int G, const double *delays, in
         band_variances(primary(h), vary);
         gpccfit::initial_params(L, R, C, rhomin, rhomax, seed, vary, cands.data());
     }
+    // a multi-device handle shards the FIT BY DELAY (README.md:195-211, :258-287: pmap over candidate delays, one gpcc per worker):
+    // every device runs its own lock-step optimiser over its delays, with every fast path of a single-device fit; one gather at the end
+    if (h->is_multi())
+        return multi_grid_loglik(h, G, delays, iterations, R, C, rhomin, rhomax, cands.data(), loglik_out, alpha_out, rho_out, info_out,
+                                 iterations_out, stats_out);
     FitEval ev{h, delays, R, L, rhomin, rhomax, {}, {}, {}, {}, {}};
-    const bool small_fit = !h->is_multi() && small_path(h);
+    const bool small_fit = small_path(h);
     if (small_fit && h->fit_device_unpack) {   // the candidate-delay table lives on the device for the duration of the fit
         GPCC_ON_DEVICE(h, h->device);
         if ((long)G * L > h->cand_cap) {
@@ -1795,20 +1837,22 @@ static void multi_free_buffers(gpcc_handle_t h)
     h->gather_cap = 0;
 }
 
-static int multi_ensure_buffers(gpcc_handle_t h, long blk)
+// gather buffers for blocks of `blk` evaluations of `width` doubles each (2: [loglik | info] of a batch; L + 4: a fitted delay)
+static int multi_ensure_buffers(gpcc_handle_t h, long blk, int width = 2)
 {
-    if (blk <= h->gather_cap) return 0;
+    const long need = blk * width;
+    if (need <= h->gather_cap) return 0;
     multi_free_buffers(h);
     const size_t n = h->subs.size();
     h->d_send.assign(n, nullptr);
     h->d_recv.assign(n, nullptr);
     for (size_t i = 0; i < n; ++i) {
         GPCC_ON_DEVICE(h, h->subs[i]->device);
-        HIPCHK(h, hipMalloc(&h->d_send[i], sizeof(double) * 2 * blk));
-        HIPCHK(h, hipMalloc(&h->d_recv[i], sizeof(double) * 2 * blk * n));
+        HIPCHK(h, hipMalloc(&h->d_send[i], sizeof(double) * need));
+        HIPCHK(h, hipMalloc(&h->d_recv[i], sizeof(double) * need * n));
     }
-    h->h_gather.resize((size_t)2 * blk * n);
-    h->gather_cap = blk;
+    h->h_gather.resize((size_t)need * n);
+    h->gather_cap = need;
     return 0;
 }
 
@@ -1872,6 +1916,47 @@ extern "C" int gpcc_create_multi(gpcc_handle_t *out, int L, const int *Nl, const
     return 0;
 }
 
+// events around every device's share (statistics) and the persistent worker threads, one per device: created on first use
+static int multi_start(gpcc_handle_t h)
+{
+    const int n = (int)h->subs.size();
+    if (h->ev_a.empty()) {
+        // created into locals and published only when ALL exist: a failure half-way must not leave null events behind for later calls
+        std::vector<hipEvent_t> ea(n, nullptr), eb(n, nullptr);
+        hipError_t ce = hipSuccess;
+        for (int i = 0; i < n && ce == hipSuccess; ++i) {
+            DeviceGuard dg(nullptr, h->subs[i]->device);
+            ce = hipEventCreate(&ea[i]);
+            if (ce == hipSuccess) ce = hipEventCreate(&eb[i]);
+        }
+        if (ce != hipSuccess) {
+            for (int i = 0; i < n; ++i) {
+                DeviceGuard dg(nullptr, h->subs[i]->device);
+                if (ea[i]) hipEventDestroy(ea[i]);
+                if (eb[i]) hipEventDestroy(eb[i]);
+            }
+            return fail(h, GPCC_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(ce));
+        }
+        h->ev_a.swap(ea);
+        h->ev_b.swap(eb);
+        h->stat_compute_ms.assign(n, 0.0);
+    }
+    if (h->workers.empty() && !h->workers_failed && n > 1) {
+        try {
+            for (int i = 0; i < n; ++i) {
+                h->workers.emplace_back(new MultiWorker());
+                MultiWorker *w = h->workers.back().get();
+                w->th = std::thread([w] { w->loop(); });
+            }
+        } catch (...) {   // no threads to be had: fall back to the calling thread (the library never throws across the C ABI)
+            for (auto &w : h->workers) w->shutdown();
+            h->workers.clear();
+            h->workers_failed = true;
+        }
+    }
+    return 0;
+}
+
 // one device's share of a batch: evaluations [lo, lo + cnt) -> d_send[i] = [loglik(blk) | info(blk)], stream-ordered
 static int multi_worker(gpcc_handle_t h, int i, long blk, long lo, int cnt, const double *delays, const double *alpha,
                         const double *rho)
@@ -1905,29 +1990,8 @@ static int multi_loglik_batch(gpcc_handle_t h, int M, const double *delays, cons
     int rc = multi_ensure_buffers(h, blk);
     if (rc) return rc;
     const auto t_begin = std::chrono::steady_clock::now();
-    if (h->ev_a.empty()) {
-        h->ev_a.assign(n, nullptr);
-        h->ev_b.assign(n, nullptr);
-        h->stat_compute_ms.assign(n, 0.0);
-        for (int i = 0; i < n; ++i) {
-            GPCC_ON_DEVICE(h, h->subs[i]->device);
-            HIPCHK(h, hipEventCreate(&h->ev_a[i]));
-            HIPCHK(h, hipEventCreate(&h->ev_b[i]));
-        }
-    }
-    if (h->workers.empty() && !h->workers_failed && n > 1) {
-        try {
-            for (int i = 0; i < n; ++i) {
-                h->workers.emplace_back(new MultiWorker());
-                MultiWorker *w = h->workers.back().get();
-                w->th = std::thread([w] { w->loop(); });
-            }
-        } catch (...) {   // no threads to be had: fall back to the calling thread (the library never throws across the C ABI)
-            for (auto &w : h->workers) w->shutdown();
-            h->workers.clear();
-            h->workers_failed = true;
-        }
-    }
+    rc = multi_start(h);
+    if (rc) return rc;
     std::vector<int> rcs(n, 0);
     for (int i = 0; i < n; ++i) {
         const long lo = (long)i * blk;
@@ -1949,6 +2013,7 @@ static int multi_loglik_batch(gpcc_handle_t h, int M, const double *delays, cons
         }
     const auto t_gather = std::chrono::steady_clock::now();
     h->gather_blk = blk;
+    h->gather_width = 2;
     const size_t nb = sizeof(double) * 2 * blk;
     if (h->gather_mode == GPCC_GATHER_RCCL) {
         // THE collective of the path: every device contributes its block and receives all of them
@@ -1995,6 +2060,129 @@ static int multi_loglik_batch(gpcc_handle_t h, int M, const double *delays, cons
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// The per-delay FIT on a multi-device handle (round 4): sharded BY DELAY, one gather at the end.  The reference parallelises the
+// fit over candidate delays (README.md:195-211, :258-287: pmap, one gpcc per worker), and SURVEY 8(e) asks for round-robin chunks
+// because iteration counts differ from delay to delay: device i takes the delays g = i, i + n, i + 2n, ... and runs gpcc_grid_loglik
+// on ITS single-device handle, on its persistent worker thread -- its own lock-step optimiser with every fast path of a
+// single-device fit (device-side unpack, speculative rounds, threaded slices on the small-N path).  Every delay sees the same random
+// candidates (each reference gpcc call seeds its own generator) and its evaluations do not depend on what else is in a batch, so a
+// delay's result is the single-device fit's bit for bit (small-N path; to rounding where the tile kernels pick their path by group
+// size).  Then ONE collective: every device contributes its block of [loglik | info | iterations | rho | alpha(L)] rows and receives
+// all of them (RCCL all-gather over xGMI; through host memory when device ids repeat), as after a batch (gpcc_multi_gathered).
+// Until round 3 every optimiser ROUND was a sharded batch: n thread hand-offs, n stream syncs and a gather 150-800 times per fit.
+// ------------------------------------------------------------------------------------------
+static int multi_grid_loglik(gpcc_handle_t h, int G, const double *delays, int iterations, int R, int C, double rhomin, double rhomax,
+                            const double *cands, double *loglik_out, double *alpha_out, double *rho_out, int *info_out,
+                            int *iterations_out, long long *stats_out)
+{
+    const int n = (int)h->subs.size(), L = h->subs[0]->L, W = L + 4;
+    const long blk = ((long)G + n - 1) / n;
+    int rc = multi_ensure_buffers(h, blk, W);
+    if (rc) return rc;
+    const auto t_begin = std::chrono::steady_clock::now();
+    rc = multi_start(h);
+    if (rc) return rc;
+    struct Share {
+        std::vector<double> delays, ll, alpha, rho, row;
+        std::vector<int> info, its;
+        long long stats[2] = {0, 0};
+        double ms = 0.0;
+    };
+    std::vector<Share> sh(n);
+    std::vector<int> rcs(n, 0);
+    for (int i = 0; i < n; ++i) {
+        Share &s = sh[i];
+        const long Gi = (G > i) ? ((long)G - i + n - 1) / n : 0;
+        s.delays.resize((size_t)Gi * L); s.ll.resize(Gi); s.alpha.resize((size_t)Gi * L); s.rho.resize(Gi); s.info.resize(Gi); s.its.resize(Gi);
+        for (long j = 0; j < Gi; ++j) memcpy(&s.delays[(size_t)j * L], delays + ((size_t)j * n + i) * L, sizeof(double) * L);
+        auto job = [h, i, Gi, iterations, R, C, rhomin, rhomax, cands, blk, W, L, &sh]() -> int {
+            Share &s = sh[i];
+            gpcc_handle_t sub = h->subs[i];
+            const auto t0 = std::chrono::steady_clock::now();
+            int r = Gi > 0 ? gpcc_grid_loglik(sub, (int)Gi, s.delays.data(), iterations, R, C, rhomin, rhomax, 0, cands, s.ll.data(),
+                                              s.alpha.data(), s.rho.data(), s.info.data(), s.its.data(), s.stats)
+                           : 0;
+            if (r) return r;
+            s.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            // this device's block of the gather: rows [loglik | info | iterations | rho | alpha(L)], padding NaN / 0
+            s.row.assign((size_t)blk * W, 0.0);
+            for (long j = 0; j < blk; ++j) {
+                double *q = &s.row[(size_t)j * W];
+                if (j < Gi) {
+                    q[0] = s.ll[j]; q[1] = (double)s.info[j]; q[2] = (double)s.its[j]; q[3] = s.rho[j];
+                    for (int l = 0; l < L; ++l) q[4 + l] = s.alpha[(size_t)j * L + l];
+                } else {
+                    q[0] = std::numeric_limits<double>::quiet_NaN();
+                }
+            }
+            GPCC_ON_DEVICE(sub, sub->device);
+            HIPCHK(sub, hipMemcpyAsync(h->d_send[i], s.row.data(), sizeof(double) * blk * W, hipMemcpyHostToDevice, sub->main_stream));
+            if (h->gather_mode == GPCC_GATHER_HOST) memcpy(h->h_gather.data() + (size_t)i * blk * W, s.row.data(), sizeof(double) * blk * W);
+            HIPCHK(sub, hipStreamSynchronize(sub->main_stream));
+            return 0;
+        };
+        if (!h->workers.empty()) h->workers[i]->submit(job);
+        else rcs[i] = job();
+    }
+    if (!h->workers.empty())
+        for (int i = 0; i < n; ++i) rcs[i] = h->workers[i]->wait();
+    for (int i = 0; i < n; ++i)
+        if (rcs[i]) return multi_fail(h, h->subs[i], rcs[i]);   // (gpcc_grid_loglik synchronises before it returns: nothing is left running)
+    const auto t_gather = std::chrono::steady_clock::now();
+    h->gather_blk = blk;
+    h->gather_width = W;
+    const size_t nb = sizeof(double) * blk * W;
+    if (h->gather_mode == GPCC_GATHER_RCCL) {
+        ncclResult_t r = ncclGroupStart();
+        for (int i = 0; i < n && r == ncclSuccess; ++i)
+            r = ncclAllGather(h->d_send[i], h->d_recv[i], (size_t)blk * W, ncclDouble, h->comms[i], h->subs[i]->main_stream);
+        const ncclResult_t r2 = ncclGroupEnd();
+        if (r == ncclSuccess) r = r2;
+        if (r != ncclSuccess) return fail(h, GPCC_ERR_HIP, "ncclAllGather failed: %s", ncclGetErrorString(r));
+        for (int i = 0; i < n; ++i) {
+            GPCC_ON_DEVICE(h, h->subs[i]->device);
+            HIPCHK(h, hipStreamSynchronize(h->subs[i]->main_stream));
+        }
+        GPCC_ON_DEVICE(h, h->subs[0]->device);
+        HIPCHK(h, hipMemcpy(h->h_gather.data(), h->d_recv[0], nb * n, hipMemcpyDeviceToHost));
+    } else {
+        for (int i = 0; i < n; ++i) {
+            GPCC_ON_DEVICE(h, h->subs[i]->device);
+            HIPCHK(h, hipMemcpyAsync(h->d_recv[i], h->h_gather.data(), nb * n, hipMemcpyHostToDevice, h->subs[i]->main_stream));
+        }
+        for (int i = 0; i < n; ++i) {
+            GPCC_ON_DEVICE(h, h->subs[i]->device);
+            HIPCHK(h, hipStreamSynchronize(h->subs[i]->main_stream));
+        }
+    }
+    long long f_calls = 0, rounds = 0;
+    for (int i = 0; i < n; ++i) {
+        const long Gi = (G > i) ? ((long)G - i + n - 1) / n : 0;
+        const double *src = h->h_gather.data() + (size_t)i * blk * W;
+        for (long j = 0; j < Gi; ++j) {
+            const long g = j * n + i;
+            const double *q = src + (size_t)j * W;
+            loglik_out[g] = q[0];
+            info_out[g] = (int)q[1];
+            if (iterations_out) iterations_out[g] = (int)q[2];
+            rho_out[g] = q[3];
+            for (int l = 0; l < L; ++l) alpha_out[(size_t)g * L + l] = q[4 + l];
+        }
+        f_calls += sh[i].stats[0];
+        rounds = std::max(rounds, sh[i].stats[1]);   // the devices advance side by side
+        h->stat_compute_ms[i] = sh[i].ms;            // (host wall clock of the device's whole fit)
+    }
+    if (stats_out) {
+        stats_out[0] = f_calls;
+        stats_out[1] = rounds;
+    }
+    const auto t_end = std::chrono::steady_clock::now();
+    h->stat_gather_ms = std::chrono::duration<double, std::milli>(t_end - t_gather).count();
+    h->stat_total_ms = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
+    return 0;
+}
+
 // per-device time of the last gpcc_loglik_batch on a multi-device handle (HIP events on each device's stream around its
 // share), the time of the gather phase (all-gather + final copies; in the host-gather mode the device-to-host copies run
 // inside the shares) and of the whole call (host wall clock): one run of a multi-GPU benchmark then shows WHERE a scaling
@@ -2015,7 +2203,7 @@ extern "C" int gpcc_multi_gathered(gpcc_handle_t h, int which, long *blk_out, do
 {
     if (!h || !h->is_multi()) return fail(h, GPCC_ERR_ARGUMENT, "not a multi-device handle");
     if (which < 0 || which >= (int)h->subs.size()) return fail(h, GPCC_ERR_ARGUMENT, "device index %d outside [0,%d)", which, (int)h->subs.size());
-    const long total = 2 * h->gather_blk * (long)h->subs.size();
+    const long total = h->gather_width * h->gather_blk * (long)h->subs.size();
     if (blk_out) *blk_out = h->gather_blk;
     if (!out) return 0;
     if (capacity < total) return fail(h, GPCC_ERR_ARGUMENT, "capacity %ld < %ld", capacity, total);

@@ -2383,7 +2383,11 @@ __global__ __launch_bounds__(256) void gpcc_refine_partials(GpccCtx c, GpccGroup
             const int j = half * 64 + jj;
             const double d = ur - su[1][j];
             const double t = (KID == 1) ? (d * d) * kscale : fabs(d) * kscale;
+#ifdef GPCC_AB_POLY_EXP   /* A/B builds only (tools/ab_exp.sh) */
+            double kv = gpcc_exp_nonpos(-t);
+#else
             double kv = gpcc_exp_nonpos_tab(-t, sexp);
+#endif
             if (KID == 2) kv *= 1.0 + t;
             else if (KID == 3) kv *= fma(t, fma(t, 1.0 / 3.0, 1.0), 1.0);
 #pragma unroll
@@ -2529,7 +2533,8 @@ template <int KID>
 __global__ void gpcc_covariance_kernel(long nx, long ny, const double *xu, const double *xs, const double *yu,
                                        const double *ys, double rho, double *out)
 {
-    __shared__ double sexp[64];   // the assembly's exp (table + degree-5 polynomial): this entry is also how tests reach it
+    __shared__ double sexp[64];   // the table exp (2^(j/64) table + degree-5 polynomial; the refinement pass uses it too, the assembly kept
+                                  // the degree-13 polynomial): this entry is how tests reach it
     GPCC_EXP_TABLE_TO_LDS(sexp, threadIdx.x);
     __syncthreads();
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,5 +1,6 @@
 // gpcc_small_inst.hip -- the instantiations of the small-N kernel families (gpcc_small.hip.h), compiled by build.py once per
 // (family, kernel id): -DGPCC_INST_WIDE=0|1 -DGPCC_INST_KID=0..3 -> one object each, eight in parallel.
+#include <atomic>
 #include "gpcc_small.hip.h"
 
 #ifndef GPCC_INST_KID
@@ -38,13 +39,15 @@ template <int NB, int WGS>
 static hipError_t launch_one(const GpccCtx &c, const GpccGroup &g, hipStream_t s)
 {
     constexpr int bytes = GpccSmallWLds<NB, 4>::bytes;
-    static bool attr_done[64] = {};   // per device (the attribute belongs to a device and a function)
+    // per device (the attribute belongs to a device and a function); the fit's slice threads launch concurrently, so the flags are
+    // atomics: two threads may both set the (idempotent) attribute, none reads a torn flag
+    static std::atomic<bool> attr_done[64];
     int dev = 0;
     hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+    if (dev >= 0 && dev < 64 && !attr_done[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void *)gpcc_smallw_eval<NB, KID, 4, WGS>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
-        attr_done[dev] = true;
+        attr_done[dev].store(true, std::memory_order_release);
     }
     gpcc_smallw_eval<NB, KID, 4, WGS><<<g.cnt, 256, bytes, s>>>(c, g);
     return hipGetLastError();

@@ -75,7 +75,10 @@ int gpcc_create_multi(gpcc_handle_t *handle, int L, const int *Nl, const double 
 
 /* The gathered vector of the last gpcc_loglik_batch as it sits on device `which` of a multi-device handle:
  * n_devices blocks of [loglik(blk) | info-as-double(blk)], blk = ceil(M / n_devices) written to *blk_out
- * (out == NULL only queries blk). */
+ * (out == NULL only queries blk).  After gpcc_grid_loglik on a multi-device handle (round 4: the fit is sharded BY DELAY, device i
+ * fits the delays i, i + n, i + 2n, ... with its own lock-step optimiser, and the results are collected by ONE all-gather):
+ * n_devices blocks of blk = ceil(G / n_devices) rows [loglik, info, iterations, rho, alpha(L)], i.e. gpcc_get_option("gather_width")
+ * = L + 4 doubles per row instead of 2 x blk. */
 int gpcc_multi_gathered(gpcc_handle_t handle, int which, long *blk_out, double *out, long capacity);
 
 /* Timing of the last gpcc_loglik_batch on a multi-device handle: compute_ms[n_devices] = each device's share on its own
@@ -117,7 +120,9 @@ int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms
  * on the small-N path), "trsm_rows_jobs" (0: three-kernel steps with at most this many panel-solve jobs use quarter-tile jobs),
  * "update_t" (0: the three-kernel path with the fused kernel's transposed main loop as its update).
  * gpcc_get_option also answers "N", "Np", "precision", "bytes_per_slot", "share_tiles", "n_devices", "gather_mode",
- * "small_n_max" (383), "small_n_active", "small_n_count". */
+ * "small_n_max" (383), "small_n_active", "small_n_count", "gather_width", "workspace_streams" / "workspace_slots" (what the workspace
+ * really holds: smaller than "streams" / "slots_per_stream" only if the device's memory was short when it was allocated -- then
+ * gpcc_last_error carries a note; the options themselves are never rewritten). */
 int gpcc_set_option(gpcc_handle_t handle, const char *key, long value);
 long gpcc_get_option(gpcc_handle_t handle, const char *key);
 

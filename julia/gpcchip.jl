@@ -11,8 +11,10 @@ using Random, Statistics, LinearAlgebra, Distributions, MiscUtil    # all alread
 const LIB = get(ENV, "GPCC_HIP_LIB", "libgpcc_hip.so")
 
 # kernel function identity -> id (src/util.jl:15-52); any other callable stays on the Julia path
-kernelid(k) = k === Main.GPCC.OU ? 0 : k === Main.GPCC.rbf ? 1 :
-              k === Main.GPCC.matern32 ? 2 : k === Main.GPCC.matern52 ? 3 : -1
+# (`include`d from src/GPCC.jl, this module's parent IS GPCC -- `Main.GPCC` would only exist after `using GPCC` in Main)
+const _G = parentmodule(@__MODULE__)
+kernelid(k) = k === _G.OU ? 0 : k === _G.rbf ? 1 :
+              k === _G.matern32 ? 2 : k === _G.matern52 ? 3 : -1
 
 lasterror(h) = unsafe_string(ccall((:gpcc_last_error, LIB), Cstring, (Ptr{Cvoid},), h))
 

@@ -35,6 +35,14 @@ def _rel(a, b):
     return np.max(np.abs(np.asarray(a) - np.asarray(b)) / np.abs(np.asarray(b)))
 
 
+def _capi_last_error(obj):
+    from gpcc_amd import _capi
+    lib = _capi.load()
+    import ctypes
+    lib.gpcc_last_error.restype = ctypes.c_char_p
+    return lib.gpcc_last_error(obj._h) or b""
+
+
 def test_selftest_mfma_map_and_rate(gp):
     tf = gp.selftest(0)
     print("fp64 MFMA rate: %.1f TFLOP/s" % tf)
@@ -132,6 +140,34 @@ def test_model_matrix_and_factor_vs_oracle(gp, oracle):
                     assert info == 0 and iref == 0
                     assert np.max(np.abs(Lf - Lref)) <= 1e-9 * np.max(np.abs(Lref))
                     assert np.array_equal(Lf, np.tril(Lf))
+
+
+@pytest.mark.parametrize("prec", ["fp64", "fp32"])
+def test_same_band_select_free_tiles_elementwise(gp, oracle, prec):
+    """The select-free assembly path (a tile whose rows lie in ONE band and whose columns lie in ONE band, off the diagonal) with
+    the `+ Sigma_b` term of a SAME-band tile (marginaliseb.jl:94-96, :135): bands of 400 and 150 points put tiles (1,0), (2,0), (2,1)
+    wholly inside band 1 -- all four kernels, elements against the oracle at 1e-13 (fp64).  fp32 handles assemble K0 without B
+    (it enters through the capacitance matrix) and evaluate these tiles in fp32: the exported matrix there is K0 rounded, 1e-6."""
+    from gpcc_amd import synthetic
+    Nl = [400, 150]
+    t, y, s, _ = synthetic.simulate_lightcurves(Nl, seed=31)
+    delays, alpha, rho = [0.0, 2.2], [1.3, 0.6], 3.1
+    for kname in ("OU", "rbf", "matern32", "matern52"):
+        with gp.Objective(t, y, s, kname, marginalise_b=True, precision=prec, slots_per_stream=2) as obj:
+            K = obj.model_matrix(delays, alpha, rho)          # (the dense utilities run the literal fp64 model on every handle)
+            Kref, _ = oracle.model_matrix(kname, t, y, s, delays, alpha, rho, True)
+            big = np.abs(Kref) > 1e-30
+            np.testing.assert_allclose(K[big], Kref[big], rtol=1e-13)
+            # (elements e^-x deep in the tail carry the relative error of their ARGUMENT times x -- the device multiplies by a
+            # per-evaluation 1/rho where the reference divides: 1e-16 x 600 at 1e-260, immaterial)
+            np.testing.assert_allclose(K, Kref, rtol=1e-12, atol=1e-300)
+            _, Sb, _ = obj.constants()
+            blk = K[128:384, 0:128] - oracle.model_matrix(kname, t, y, s, delays, alpha, rho, False)[0][128:384, 0:128]
+            np.testing.assert_allclose(blk, np.full_like(blk, Sb[0]), rtol=1e-10)   # the tile really carries + Sigma_b[band 1]
+            ll, info = obj.loglik_batch([delays], [alpha], [rho])
+            ref, rinfo = oracle.loglik_batch(kname, t, y, s, [delays], [alpha], [rho], True)
+            assert info[0] == 0 and rinfo[0] == 0
+            assert abs(ll[0] - ref[0]) <= (LL_RTOL if prec == "fp64" else 1e-3) * abs(ref[0])
 
 
 @pytest.mark.parametrize("kname", ["OU", "rbf", "matern32", "matern52"])
@@ -988,6 +1024,8 @@ def test_workspace_shrinks_when_the_memory_has_gone(gp):
             obj.set_option(k, v)
         ref, rinfo = obj.loglik_batch(delays, alphas, rhos)
         want = obj.get_option("streams") * obj.get_option("slots_per_stream") * obj.get_option("bytes_per_slot")
+        assert obj.get_option("workspace_streams") == obj.get_option("streams")          # nothing shrank here
+        assert obj.get_option("workspace_slots") == obj.get_option("slots_per_stream")
     assert (rinfo == 0).all() and want > 3 << 30
     with gp.Objective(t, y, s, gp.matern32) as obj:              # created while the memory is free ...
         for k, v in (("hybrid_tail", 0), ("split_min", 0)):
@@ -999,8 +1037,11 @@ def test_workspace_shrinks_when_the_memory_has_gone(gp):
         except RuntimeError as e:                                                       # (not this test's subject)
             pytest.skip("could not occupy the GPU's memory: %s" % str(e)[:80])
         try:
+            opts = (obj.get_option("streams"), obj.get_option("slots_per_stream"))
             ll, info = obj.loglik_batch(delays, alphas, rhos)
-            got = obj.get_option("streams") * obj.get_option("slots_per_stream") * obj.get_option("bytes_per_slot")
+            got = obj.get_option("workspace_streams") * obj.get_option("workspace_slots") * obj.get_option("bytes_per_slot")
+            assert (obj.get_option("streams"), obj.get_option("slots_per_stream")) == opts   # the caller's options are NOT rewritten ...
+            assert b"workspace runs" in _capi_last_error(obj)                                 # ... and the shrink is reported
         finally:
             del hog
             torch.cuda.empty_cache()

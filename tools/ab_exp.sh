@@ -3,7 +3,8 @@
 # beside the default one (2^(j/64) table + degree-5 polynomial) and runs the same bench lines with each.  Run via gpurun.
 set -e
 cd $GRAFT_REPO_ROOT
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value -DGPCC_AB_POLY_EXP -o /tmp/libgpcc_poly.so gpcc.jl_amd/csrc/gpcc_hip.hip -L/opt/rocm/lib -lrccl -pthread 2>/dev/null
+# the A/B library through the package's own build (ten objects, gpcc.jl_amd/build.py), into its own file
+GPCC_HIP_LIB=/tmp/libgpcc_poly.so GPCC_BUILD_DEFINES="-DGPCC_AB_POLY_EXP" python3 -c "import sys; sys.path.insert(0, '.'); from gpcc_amd import build; print(build.build(force=True))"
 for rep in 1 2; do
 for lib in "" /tmp/libgpcc_poly.so; do
   tag=${lib:+poly}; tag=${tag:-table}
