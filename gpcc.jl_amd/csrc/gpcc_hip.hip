@@ -112,6 +112,7 @@ struct gpcc_handle_s {
     double *d_t = nullptr, *d_sig2 = nullptr, *d_resid = nullptr, *d_yv = nullptr;
     int *d_band = nullptr;
     std::vector<double> t_host, y_host, sig2_host;
+    double tmid = 0.0;       // midpoint of the observation times (GpccCtx::tmid)
     std::vector<int> band_host;
     // options
     int streams = 2;         // groups of a batch alternate between this many streams: the next group's assembly and first steps fill
@@ -371,6 +372,11 @@ extern "C" int gpcc_create(gpcc_handle_t *out, int L, const int *Nl, const doubl
             hy[off + n] = y[off + n];
         }
         off += Nl[l];
+    }
+    {
+        double lo = t[0], hi = t[0];
+        for (long i = 1; i < N; ++i) { lo = std::min(lo, t[i]); hi = std::max(hi, t[i]); }
+        h->tmid = 0.5 * (lo + hi);
     }
     h->resid_host.assign(hr.begin(), hr.begin() + N);
     h->t_host.assign(ht.begin(), ht.begin() + N);
@@ -675,6 +681,7 @@ static GpccCtx make_ctx(gpcc_handle_t h)
     c.kdiag = h->d_kdiag; c.cond = h->d_cond; c.gpart = h->d_gpart;
     c.linv_keep = (h->precision == GPCC_PRECISION_FP32) ? 1 : 2;
     c.t = h->d_t; c.sig2 = h->d_sig2; c.resid = h->d_resid; c.band = h->d_band; c.yv = h->d_yv;
+    c.tmid = h->tmid;
     for (int l = 0; l < GPCC_MAXL; ++l) c.sigma_b[l] = (l < h->L) ? h->sigma_b[l] : 0.0;
     c.slot_stride = h->slot_stride;
     c.L = h->L; c.N = h->N; c.Np = h->Np; c.nt = h->nt; c.kernel_id = h->kernel_id; c.marginalise_b = h->mb;

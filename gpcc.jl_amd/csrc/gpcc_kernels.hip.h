@@ -75,6 +75,7 @@ struct GpccCtx {
     double *kdiag;   // slots x Np : diag(K) as assembled, fp64 (fp32 mode only: numerator of the pivot ratios below)
     double *cond;    // slots x 2  : sum_i K_ii / d_i and max_i K_ii / d_i over the pivots d_i (fp32 mode only) -- the
                      //              a-posteriori conditioning measure behind the fp64 re-evaluation, DESIGN.md 4.7
+    double tmid;     // midpoint of the observation times: centre of the separable-exponential form (gpcc_sep_point)
     const double *t, *sig2, *resid;  // Np (padding: 0)
     const double *yv;                // Np: raw fluxes (only read by explicit 'Y' rows, see band codes)
     const int *band;                 // Np: >= 0 band of a real point; -1 identity padding;
@@ -297,6 +298,68 @@ __device__ __forceinline__ double gpcc_kernel_eval_scaled(double xi, double xj, 
 }
 
 // ------------------------------------------------------------------------------------------
+// The exponential kernels are SEPARABLE (round 4): for OU / Matern-3/2 / Matern-5/2 the element is a polynomial in t = s |u_i - u_j|
+// times exp(-t), and
+//     a_i a_j exp(-s |u_i - u_j|) = min(A_i B_j, A_j B_i),   A_p = a_p exp(-s (u_p - c)),   B_p = a_p exp(+s (u_p - c))
+// (one of the two products is a a' e^-t, the other a a' e^+t; c any constant).  So the N^2 exponentials of an evaluation -- 19 of the
+// ~28 double-precision operations of an element, what bounds the assembly (4.6 of 8 TB/s), the fp32 refinement pass and a quarter of
+// a small-N evaluation -- become 2 N exponentials per evaluation (per tile: 512 instead of 16 384) and two multiplications and a
+// minimum per element.  Accuracy: the argument s (u - c) is carried as a double-double (TwoSum of u - c, fma for the product), so
+// A_p and B_p are good to ~2 ulp whatever the magnitude of the argument and an element to ~4 ulp -- plus |t| ulp(s) from the
+// rounded scale s, which the direct form has too.  Range: |s (u - c)| <= GPCC_SEP_MAX keeps A, B finite; a product may overflow to
+// +inf (the minimum then picks the other) or underflow to 0 where the true value is below 1e-520.  Outside the range -- and for rbf,
+// which is not of this form -- the direct evaluation is used (decided per tile resp. per evaluation, uniformly).
+// ------------------------------------------------------------------------------------------
+#define GPCC_SEP_MAX 600.0
+__device__ __forceinline__ double gpcc_exp_dd(double hi, double lo)   // exp(hi + lo), |lo| << 1, |hi| <~ 700
+{
+    const double L2E = 1.4426950408889634074, LN2HI = 6.93147180369123816490e-01, LN2LO = 1.90821492927058770002e-10;
+    const double n = rint(hi * L2E);
+    double r = fma(-n, LN2HI, hi);
+    r = fma(-n, LN2LO, r);
+    r += lo;
+    double p = 1.6059043836821614599e-10;  // 1/13!
+    p = fma(p, r, 2.0876756987868098979e-09);
+    p = fma(p, r, 2.5052108385441718775e-08);
+    p = fma(p, r, 2.7557319223985890653e-07);
+    p = fma(p, r, 2.7557319223985890653e-06);
+    p = fma(p, r, 2.4801587301587301587e-05);
+    p = fma(p, r, 1.9841269841269841270e-04);
+    p = fma(p, r, 1.3888888888888888889e-03);
+    p = fma(p, r, 8.3333333333333333333e-03);
+    p = fma(p, r, 4.1666666666666666667e-02);
+    p = fma(p, r, 1.6666666666666666667e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double nn = fmin(fmax(n, -1100.0), 1100.0);
+    return ldexp(p, (int)nn);
+}
+// A = amp exp(-s (u - c)), B = amp exp(+s (u - c)); returns false (A, B undefined) if the argument is out of range
+__device__ __forceinline__ bool gpcc_sep_point(double u, double c, double s, double amp, double &A, double &B)
+{
+#pragma clang fp contract(off)
+    const double w = u - c;                         // TwoSum: u - c = w + wl exactly
+    const double bb = w - u;
+    const double wl = (u - (w - bb)) + (-c - bb);
+    const double p = s * w;                         // s (u - c) = p + e to ~2^-104 relative
+    const double e = __builtin_fma(s, w, -p) + s * wl;
+    A = amp * gpcc_exp_dd(-p, -e);
+    B = amp * gpcc_exp_dd(p, e);
+    return fabs(p) <= GPCC_SEP_MAX;
+}
+// the element from the separable factors: aa' k(u_i, u_j) with t = s |u_i - u_j|   (KID 0 OU, 2 Matern-3/2, 3 Matern-5/2)
+template <int KID>
+__device__ __forceinline__ double gpcc_sep_eval(double ui, double uj, double Ai, double Bi, double Aj, double Bj, double s)
+{
+    const double e = fmin(Ai * Bj, Aj * Bi);
+    if (KID == 0) return e;
+    const double t = fabs(ui - uj) * s;
+    if (KID == 2) return fma(e, t, e);
+    return e * fma(t, fma(t, 1.0 / 3.0, 1.0), 1.0);
+}
+
+// ------------------------------------------------------------------------------------------
 // gpcc_assemble_tiles: K = delayedCovariance + Sobs (+ B) for `cnt` evaluations, written once,
 // lower-triangle tiles only, 16 B per lane fully coalesced (a workgroup store instruction
 // covers 4 KiB contiguous).  HBM-write-bound: sizeof(T) * 128*128 * nt(nt+1)/2 bytes per evaluation.
@@ -309,7 +372,7 @@ __device__ __forceinline__ double gpcc_kernel_eval_scaled(double xi, double xj, 
 __device__ __forceinline__ bool diag_tile(int I, int J) { return I == J; }
 
 template <int KID, bool EXT, typename T>
-__global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup g)
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 4) void gpcc_assemble_tiles(GpccCtx c, GpccGroup g)
 {
     typedef GpccPrec<T> P;
     const int I = blockIdx.x / c.nt, J = blockIdx.x % c.nt;
@@ -323,9 +386,11 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
     const double rho = g.rho[g.first + m];
 
     __shared__ __attribute__((aligned(16))) double su[2][GPCC_TILE], sa[2][GPCC_TILE], ssig[GPCC_TILE], ssb[GPCC_MAXL];
+    __shared__ __attribute__((aligned(16))) double sA[2][GPCC_TILE], sB[2][GPCC_TILE];   // separable factors (gpcc_sep_point)
     __shared__ int sb[2][GPCC_TILE];
     __shared__ double syv[EXT ? GPCC_TILE : 1];   // fluxes of the tile's columns (explicit 'Y' rows only)
     if (tid < GPCC_MAXL) ssb[tid] = (tid < c.L) ? c.sigma_b[tid] : 0.0;
+    bool sep_ok = true;   // this thread's point is inside the range of the separable form
 
     if (I == first_row && J == 0 && tid == 0) {  // per-slot state + the reference's argument checks
         int bad = 0;
@@ -342,8 +407,16 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
         const int gi = (side ? J : I) * GPCC_TILE + r;
         const int b = c.band[gi];
         sb[side][r] = b;
-        su[side][r] = (b >= 0) ? c.t[gi] - delays[b] : 0.0;  // x - delays[i], delayedCovariance.jl:27
-        sa[side][r] = (b >= 0) ? alpha[b] : 0.0;
+        const double u_ = (b >= 0) ? c.t[gi] - delays[b] : 0.0;  // x - delays[i], delayedCovariance.jl:27
+        const double a_ = (b >= 0) ? alpha[b] : 0.0;
+        su[side][r] = u_;
+        sa[side][r] = a_;
+        if (KID != 1 && I != J) {   // (off-diagonal tiles only: the select-free path below is the one that uses them)
+            double A_, B_;
+            sep_ok = gpcc_sep_point(u_, c.tmid, gpcc_kernel_scale<KID>(kc), a_, A_, B_);
+            sA[side][r] = A_;
+            sB[side][r] = B_;
+        }
         if (side == 0) {
             ssig[r] = c.sig2[gi];
             if (I == J) {  // right-hand sides: z <- Y - bbar (last column), woodbury: the columns of Q before it
@@ -355,7 +428,7 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
             syv[r] = c.yv[gi];
         }
     }
-    __syncthreads();
+    const bool sep = __syncthreads_and(sep_ok ? 1 : 0) != 0 && KID != 1;   // (also the barrier behind the staging)
 
     T *Tt = (T *)c.tiles + (long)slot * c.slot_stride + gpcc_tile_off(I, J);
     const bool diag = (I == J);
@@ -392,6 +465,40 @@ __global__ __launch_bounds__(256) void gpcc_assemble_tiles(GpccCtx c, GpccGroup 
         // t = |u_i - u_j| * kscale (the difference first: exact for nearby points) -- the same element as gpcc_kernel_eval's to an
         // ulp or two (fewer roundings, not more), 3-6 operations and one LDS read cheaper
         const double kscale = gpcc_kernel_scale<KID>(kc);
+        if (KID != 1 && sep) {
+            // the separable form: a a' e^-t = min(A_i B_j, A_j B_i) -- no exponential per element (512 per tile instead of 16 384):
+            // 7 double-precision operations per element instead of ~28, so that the kernel is bound by its stores
+            // (a thread's four rows r, r + 32, .. share their swizzle, hence their columns: chunk by chunk, the column factors
+            //  of a chunk in registers for the four rows -- not all 16 columns x 3 arrays at once)
+            const int r0_ = tid >> 3;
+            const int cs = (sp ^ gpcc_sw(r0_)) * P::EP;
+            double ur[4], Ar[4], Br[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ur[j] = su[0][r0_ + 32 * j];
+                Ar[j] = sA[0][r0_ + 32 * j];
+                Br[j] = sB[0][r0_ + 32 * j];
+            }
+#pragma unroll 2
+            for (int ch = 0; ch < P::NCH; ++ch) {
+                const int col = ch * P::KC + cs;
+                double uc[P::EP], Ac[P::EP], Bc[P::EP];
+#pragma unroll
+                for (int h = 0; h < P::EP; ++h) {
+                    uc[h] = su[1][col + h];
+                    Ac[h] = sA[1][col + h];
+                    Bc[h] = sB[1][col + h];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    typename P::v16 v;
+#pragma unroll
+                    for (int h = 0; h < P::EP; ++h) v[h] = (T)(gpcc_sep_eval<KID>(ur[j], uc[h], Ar[j], Br[j], Ac[h], Bc[h], kscale) + bt);
+                    *(typename P::v16 *)(Tt + ch * (GPCC_TILE * P::KC) + (r0_ + 32 * j) * P::KC + sp * P::EP) = v;
+                }
+            }
+            return;
+        }
         const double acol = sa[1][0];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -2350,20 +2457,29 @@ __global__ __launch_bounds__(256) void gpcc_refine_partials(GpccCtx c, GpccGroup
     __shared__ double su[2][GPCC_TILE], sa[2][GPCC_TILE], ssig[GPCC_TILE], sx[2][GPCC_MAXRHS][GPCC_TILE];
     __shared__ int sb[2][GPCC_TILE];
     __shared__ double sred[4][GPCC_MAXRHS * GPCC_MAXRHS];
-    __shared__ double sexp[64];   // the same exp as the assembly: the elements are regenerated exactly as it computed them
+    __shared__ double sexp[64];   // the table exp (diagonal / band-straddling tiles)
+    __shared__ double sA[2][GPCC_TILE], sB[2][GPCC_TILE];   // separable factors of the tile's points (gpcc_sep_point)
     GPCC_EXP_TABLE_TO_LDS(sexp, tid);
+    bool sep_ok = true;
     {
         const int side = tid >> 7, r = tid & 127;
         const int T0 = side ? J : I, gi = T0 * GPCC_TILE + r;
         const int b = c.band[gi];
         sb[side][r] = b;
-        su[side][r] = (b >= 0) ? c.t[gi] - delays[b] : 0.0;
-        sa[side][r] = (b >= 0) ? alpha[b] : 0.0;
+        const double u_ = (b >= 0) ? c.t[gi] - delays[b] : 0.0, a_ = (b >= 0) ? alpha[b] : 0.0;
+        su[side][r] = u_;
+        sa[side][r] = a_;
+        if (KID != 1 && I != J) {
+            double A_, B_;
+            sep_ok = gpcc_sep_point(u_, c.tmid, gpcc_kernel_scale<KID>(kc), a_, A_, B_);
+            sA[side][r] = A_;
+            sB[side][r] = B_;
+        }
         if (side == 0) ssig[r] = c.sig2[gi];
         const double *X = c.z + (long)slot * nrhs * c.Np;
         for (int a = 0; a < nrhs; ++a) sx[side][a][r] = X[(long)a * c.Np + gi];
     }
-    __syncthreads();
+    const bool sep = __syncthreads_and(sep_ok ? 1 : 0) != 0 && KID != 1;
     const int i = tid & 127, half = tid >> 7;
     const bool diag = (I == J);
     const int br = sb[0][i];
@@ -2378,6 +2494,17 @@ __global__ __launch_bounds__(256) void gpcc_refine_partials(GpccCtx c, GpccGroup
         // fold into ONE scale of the distance, t = |u_i - u_j| * kscale (the difference first: it is exact for nearby points) --
         // 18 instead of 22 double-rate operations per element; the element agrees with the assembly's to an ulp or two
         const double kscale = (KID == 0) ? kc.c1 : (KID == 1) ? 0.5 * kc.c1 : (KID == 2) ? 1.7320508075688772 * kc.c1 : 2.23606797749979 * kc.c1;
+        if (KID != 1 && sep) {   // the separable form (as the assembly): no exponential per element, the amplitudes inside the factors
+            const double Ar = sA[0][i], Br = sB[0][i];
+#pragma unroll 4
+            for (int jj = 0; jj < 64; ++jj) {
+                const int j = half * 64 + jj;
+                const double kv = gpcc_sep_eval<KID>(ur, su[1][j], Ar, Br, sA[1][j], sB[1][j], kscale);
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+                    if (NR || a < nrhs) s[a] = fma(kv, sx[1][a][j], s[a]);
+            }
+        } else {
 #pragma unroll 4
         for (int jj = 0; jj < 64; ++jj) {
             const int j = half * 64 + jj;
@@ -2397,6 +2524,7 @@ __global__ __launch_bounds__(256) void gpcc_refine_partials(GpccCtx c, GpccGroup
         const double amp = ar * sa[1][0];
 #pragma unroll
         for (int a = 0; a < NA; ++a) s[a] *= amp;
+        }
     } else {
 #pragma unroll 4
         for (int jj = 0; jj < 64; ++jj) {

@@ -91,7 +91,9 @@ __device__ __forceinline__ void gpcc_small_potf2(const double *sD, double *sX, d
 
 // everything a row needs besides the register blocks (all scalarised after inlining)
 struct GpccSmallState {
-    const double *su, *sa, *ssb;
+    const double *su, *sa, *ssb;   // shifted time; amplitude -- or, with `sep`, A_p = a_p exp(-s (u_p - c)); Sigma_b of the band
+    const double *sB;              // sep: B_p = a_p exp(+s (u_p - c))   (gpcc_sep_point, gpcc_kernels.hip.h)
+    bool sep;                      // the separable-exponential form is in use for this evaluation (uniform)
     const int *sbd;
     double *sstage, *sD, *sX, *sr;
     const double *sig2, *resid;
@@ -115,12 +117,27 @@ __device__ __forceinline__ void gpcc_small_block(const GpccSmallState &st, const
     const int bc = st.sbd[gc];
     const bool edge = 16 * i + 15 >= N;   // the block holds the right-hand side and/or padding (wave-uniform)
     int br[4];
+    if (KID != 1 && st.sep) {   // (uniform) scale[i] scale[j] kernel from the separable factors: no exponential per element
+        const double bcv = st.sB[gc];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int gr = 16 * J + q + 4 * r;
-        br[r] = st.sbd[gr];
-        const double kv = gpcc_kernel_eval_scaled<KID>(st.su[gr], uc, st.kscale);   // kernel(x - delays[i], y - delays[j]; rho)
-        val[r] = (st.sa[gr] * ac) * kv;                                  // scale[i] scale[j] kernel, delayedCovariance.jl:27
+        for (int r = 0; r < 4; ++r) {
+            const int gr = 16 * J + q + 4 * r;
+            br[r] = st.sbd[gr];
+            const double e = fmin(st.sa[gr] * bcv, ac * st.sB[gr]);
+            if (KID == 0) val[r] = e;
+            else {
+                const double t = fabs(st.su[gr] - uc) * st.kscale;
+                val[r] = (KID == 2) ? __builtin_fma(e, t, e) : e * __builtin_fma(t, __builtin_fma(t, 1.0 / 3.0, 1.0), 1.0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gr = 16 * J + q + 4 * r;
+            br[r] = st.sbd[gr];
+            const double kv = gpcc_kernel_eval_scaled<KID>(st.su[gr], uc, st.kscale);   // kernel(x - delays[i], y - delays[j]; rho)
+            val[r] = (st.sa[gr] * ac) * kv;                                  // scale[i] scale[j] kernel, delayedCovariance.jl:27
+        }
     }
     if (i == J) {   // (wave-uniform) + Sobs, marginaliseb.jl:89, :135; padding: 1, right-hand-side row: 0
         const double sgc = gc < N ? st.sig2[gc] : (gc == NP - 1 ? 0.0 : 1.0);
@@ -139,6 +156,31 @@ __device__ __forceinline__ void gpcc_small_block(const GpccSmallState &st, const
             if (br[r] == -3 && bc >= 0) val[r] = st.resid[gc];
         }
     }
+}
+
+// point p of the bordered problem -> the per-point LDS arrays; returns true if the separable form cannot hold this point.
+// plain: store the amplitude itself in sa (the direct evaluation multiplies a a' k); else sa = A_p, sB = B_p (gpcc_sep_point).
+// The same function serves the one-wave and the four-wave kernel: both must see the same bits.
+template <int KID>
+__device__ __forceinline__ bool gpcc_small_point(const GpccCtx &c, int p, int N, int NP, const double *delays, const double *sal, bool mb,
+                                                 double kscale, double *su, double *sa, double *sB, double *ssb, int *sbd, bool plain)
+{
+    int b = -1;
+    double u = 0.0, a = 0.0, sb = 0.0, A = 0.0, B = 0.0;
+    bool outside = false;
+    if (p < N) {
+        b = c.band[p];
+        u = c.t[p] - delays[b];            // x - delays[i], delayedCovariance.jl:27
+        a = sal[b];
+        sb = mb ? c.sigma_b[b] : 0.0;      // B = Q Sigma_b Q', marginaliseb.jl:96, :135
+        if (KID != 1 && !plain) outside = !gpcc_sep_point(u, c.tmid, kscale, a, A, B);
+    } else if (p == NP - 1) {              // the right-hand side: always the LAST row / column (local pivot 15 of the last block)
+        b = -3;
+    }
+    sbd[p] = b; su[p] = u; ssb[p] = sb;
+    sa[p] = (KID == 1 || plain) ? a : A;
+    sB[p] = B;
+    return outside;
 }
 
 // rows J .. NB-1 by compile-time recursion (a `#pragma unroll` of this loop is refused beyond ~16k IR instructions)
@@ -239,31 +281,26 @@ __global__ __launch_bounds__(64, WPE) void gpcc_small_eval(GpccCtx c, GpccGroup 
             return;
         }
     }
-    __shared__ double su[NP], sa[NP], ssb[NP];   // shifted time, amplitude, Sigma_b of the band
+    __shared__ double su[NP], sa[NP], sB[NP], ssb[NP];   // shifted time, amplitude (or A), B, Sigma_b of the band
     __shared__ int sbd[NP];                       // band id; -1 padding; -3 the right-hand-side row
     __shared__ double sstage[SB * 4 * 64];
     __shared__ double sD[32 * DLD], sX[16 * DLD], sr[96];   // sD rows 16..31: the identity
 
     const bool mb = c.marginalise_b != 0;
-    for (int p = lane; p < NP; p += 64) {
-        int b = -1;
-        double u = 0.0, a = 0.0, sb = 0.0;
-        if (p < N) {
-            b = c.band[p];
-            u = c.t[p] - delays[b];            // x - delays[i], delayedCovariance.jl:27
-            a = sal[b];
-            sb = mb ? c.sigma_b[b] : 0.0;      // B = Q Sigma_b Q', marginaliseb.jl:96, :135
-        } else if (p == NP - 1) {              // the right-hand side: always the LAST row / column (local pivot 15 of the last block)
-            b = -3;
-        }
-        sbd[p] = b; su[p] = u; sa[p] = a; ssb[p] = sb;
+    const GpccKernelConst kc0 = gpcc_kernel_const<KID>(rho);
+    const double kscale0 = gpcc_kernel_scale<KID>(kc0);
+    bool outside = false;                         // some point's s (u - c) is beyond the range of the separable form
+    for (int p = lane; p < NP; p += 64) outside |= gpcc_small_point<KID>(c, p, N, NP, delays, sal, mb, kscale0, su, sa, sB, ssb, sbd, false);
+    const bool sep = KID != 1 && __builtin_amdgcn_ballot_w64(outside) == 0;
+    if (KID != 1 && !sep) {                       // (uniform, rare: a huge time span over a tiny length scale) plain amplitudes instead
+        for (int p = lane; p < NP; p += 64) gpcc_small_point<KID>(c, p, N, NP, delays, sal, mb, kscale0, su, sa, sB, ssb, sbd, true);
     }
     for (int e = lane; e < 16 * DLD; e += 64) sD[16 * DLD + e] = (e / DLD == e % DLD) ? 1.0 : 0.0;
     __syncthreads();
 
     GpccSmallState st;
-    st.su = su; st.sa = sa; st.ssb = ssb; st.sbd = sbd; st.sstage = sstage; st.sD = sD; st.sX = sX; st.sr = sr;
-    st.sig2 = c.sig2; st.resid = c.resid; st.kc = gpcc_kernel_const<KID>(rho); st.kscale = gpcc_kernel_scale<KID>(st.kc); st.N = N; st.lane = lane;
+    st.su = su; st.sa = sa; st.sB = sB; st.sep = sep; st.ssb = ssb; st.sbd = sbd; st.sstage = sstage; st.sD = sD; st.sX = sX; st.sr = sr;
+    st.sig2 = c.sig2; st.resid = c.resid; st.kc = kc0; st.kscale = kscale0; st.N = N; st.lane = lane;
     st.py = 1.0; st.quad = 0.0; st.pe = 0; st.bad = 0;
     d4 U[NB][NB];   // finished rows: U[m][i], i > m
     gpcc_small_rows<NB, KID, 0>(U, st);
@@ -292,12 +329,12 @@ __global__ __launch_bounds__(64, WPE) void gpcc_small_eval(GpccCtx c, GpccGroup 
 // Two barriers per row.  The running product behind sum log L_ii travels from owner to owner through LDS, so the result is the
 // one-wave kernel's bit for bit (an evaluation must not depend on the batch it travels in: the optimiser relies on it); the first
 // non-positive pivot stops every wave at the row's second barrier.
-// LDS (dynamic): point data 28 NP bytes, column buffer (NB - 1) x 2 KiB, W stages of ceil(NB / W) x 2 KiB, the diagonal step.
+// LDS (dynamic): point data 36 NP bytes, column buffer (NB - 1) x 2 KiB, W stages of ceil(NB / W) x 2 KiB, the diagonal step.
 // ------------------------------------------------------------------------------------------
 template <int NB, int W>
 struct GpccSmallWLds {
     static constexpr int NP = 16 * NB, NC = (NB + W - 1) / W, DLD = GPCC_SMALL_DLD;
-    static constexpr int o_su = 0, o_sa = o_su + NP, o_ssb = o_sa + NP, o_col = o_ssb + NP, o_stage = o_col + (NB - 1) * 256,
+    static constexpr int o_su = 0, o_sa = o_su + NP, o_sB = o_sa + NP, o_ssb = o_sB + NP, o_col = o_ssb + NP, o_stage = o_col + (NB - 1) * 256,
                          o_sD = o_stage + W * NC * 256, o_sX = o_sD + 32 * DLD, o_sr = o_sX + 16 * DLD, o_red = o_sr + 96,
                          o_sal = o_red + 2 * W + 2, o_end = o_sal + GPCC_MAXL;   // in doubles
     static constexpr int bytes = o_end * 8 + NP * 4 + 16;                        // + band ids (int) + flags
@@ -417,7 +454,7 @@ __global__ __launch_bounds__(64 * W, WGS) void gpcc_smallw_eval(GpccCtx c, GpccG
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = c.N;
-    double *su = lds + LD::o_su, *sa = lds + LD::o_sa, *ssb = lds + LD::o_ssb, *scol = lds + LD::o_col;
+    double *su = lds + LD::o_su, *sa = lds + LD::o_sa, *sB = lds + LD::o_sB, *ssb = lds + LD::o_ssb, *scol = lds + LD::o_col;
     double *sstage = lds + LD::o_stage + w * NC * 256, *sD = lds + LD::o_sD, *sX = lds + LD::o_sX, *sr = lds + LD::o_sr;
     double *sred = lds + LD::o_red, *sal = lds + LD::o_sal;
     int *sbd = (int *)(lds + LD::o_end), *sflag = sbd + NP;
@@ -435,6 +472,7 @@ __global__ __launch_bounds__(64 * W, WGS) void gpcc_smallw_eval(GpccCtx c, GpccG
     }
     if (tid == 0) {
         *sflag = 0;
+        sflag[1] = 0;    // some point outside the range of the separable form
         sred[0] = 1.0;   // running product of the mantissas of 1 / sqrt(d_j) ...
         sred[1] = 0.0;   // ... and the sum of their exponents
         sred[2] = 0.0;   // r' K^-1 r
@@ -454,25 +492,22 @@ __global__ __launch_bounds__(64 * W, WGS) void gpcc_smallw_eval(GpccCtx c, GpccG
         }
     }
     const bool mb = c.marginalise_b != 0;
-    for (int p = tid; p < NP; p += 64 * W) {
-        int b = -1;
-        double u = 0.0, a = 0.0, sb = 0.0;
-        if (p < N) {
-            b = c.band[p];
-            u = c.t[p] - delays[b];            // x - delays[i], delayedCovariance.jl:27
-            a = sal[b];
-            sb = mb ? c.sigma_b[b] : 0.0;      // B = Q Sigma_b Q', marginaliseb.jl:96, :135
-        } else if (p == NP - 1) {              // the right-hand side: always the LAST row / column
-            b = -3;
-        }
-        sbd[p] = b; su[p] = u; sa[p] = a; ssb[p] = sb;
-    }
+    const GpccKernelConst kc0 = gpcc_kernel_const<KID>(rho);
+    const double kscale0 = gpcc_kernel_scale<KID>(kc0);
+    bool outside = false;
+    for (int p = tid; p < NP; p += 64 * W) outside |= gpcc_small_point<KID>(c, p, N, NP, delays, sal, mb, kscale0, su, sa, sB, ssb, sbd, false);
+    if (KID != 1 && __builtin_amdgcn_ballot_w64(outside) != 0 && lane == 0) sflag[1] = 1;
     for (int e = tid; e < 16 * DLD; e += 64 * W) sD[16 * DLD + e] = (e / DLD == e % DLD) ? 1.0 : 0.0;
     __syncthreads();
+    const bool sep = KID != 1 && sflag[1] == 0;
+    if (KID != 1 && !sep) {                       // (uniform, rare) plain amplitudes for the direct evaluation
+        for (int p = tid; p < NP; p += 64 * W) gpcc_small_point<KID>(c, p, N, NP, delays, sal, mb, kscale0, su, sa, sB, ssb, sbd, true);
+        __syncthreads();
+    }
 
     GpccSmallState st;
-    st.su = su; st.sa = sa; st.ssb = ssb; st.sbd = sbd; st.sstage = sstage; st.sD = sD; st.sX = sX; st.sr = sr;
-    st.sig2 = c.sig2; st.resid = c.resid; st.kc = gpcc_kernel_const<KID>(rho); st.kscale = gpcc_kernel_scale<KID>(st.kc); st.N = N; st.lane = lane;
+    st.su = su; st.sa = sa; st.sB = sB; st.sep = sep; st.ssb = ssb; st.sbd = sbd; st.sstage = sstage; st.sD = sD; st.sX = sX; st.sr = sr;
+    st.sig2 = c.sig2; st.resid = c.resid; st.kc = kc0; st.kscale = kscale0; st.N = N; st.lane = lane;
     st.py = 1.0; st.quad = 0.0; st.pe = 0; st.bad = 0;
     d4 U[NB][NC];
     gpcc_smallw_rows<NB, KID, W, 0>(U, st, scol, sred, sflag, w);

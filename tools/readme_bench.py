@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--option", action="append", default=[])
     ap.add_argument("--no-fit", action="store_true")
+    ap.add_argument("--devices", default="", help="comma-separated device ids: a multi-device handle (the fit is then sharded by delay, one gather); "
+                                                  "repeated ids rehearse it on one GPU")
     ap.add_argument("--cpu-fit-points", type=int, default=0, help="> 0: also run the fit on the CPU port, on at most this many delays of each sweep")
     args = ap.parse_args()
 
@@ -104,7 +106,10 @@ def main():
         G = len(cand)
         alpha, rho = synthetic.default_hyperparameters(w["y"])
         out = {"sweep": name, "workload": w["what"], "kernel": args.kernel, "G": G}
-        with gpcc_amd.Objective(w["t"], w["y"], w["s"], args.kernel) as obj:
+        devs = [int(x) for x in args.devices.split(",")] if args.devices else None
+        if devs:
+            out["devices"] = devs
+        with gpcc_amd.Objective(w["t"], w["y"], w["s"], args.kernel, devices=devs) as obj:
             for kv in args.option:
                 k, v = kv.split("=")
                 obj.set_option(k, int(v))
@@ -133,6 +138,10 @@ def main():
                             "mean_evals_per_round": round(f_calls / rounds, 1), "info_nonzero": int((info != 0).sum()),
                             "median_iterations_done": float(np.median(its)),
                             "posterior_mode": [float(x) for x in cand[int(np.argmax(p))]]})
+                if devs:
+                    comp, gms, tms = obj.multi_stats()
+                    out["fit_per_device_ms"] = [round(float(x), 2) for x in comp]
+                    out["fit_gather_ms"] = round(gms, 3)
         if args.cpu_seconds > 0:
             rate, nthreads = cpu_port_rate(w, args.kernel, args.cpu_seconds)
             out["cpu_port_evals_per_s"] = round(rate, 1)
