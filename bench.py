@@ -111,6 +111,37 @@ def small_executed_ops(N, kernel):
             "pivot_steps_16x16": NB * 16 * (2.0 * 15 + 12.0) * 64}
 
 
+class GpuSampler:
+    """Samples gpu_state on a host thread every `period` seconds WHILE the timed region runs (a sample taken before or after it sees
+    an idle GPU at its lowest clock): -> {"sclk_mhz": [min, median, max], "power_w": [mean, max], "samples": n}."""
+
+    def __init__(self, index=0, period=0.05):
+        import threading
+        self.index, self.period, self.rows = index, period, []
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.rows.append(gpu_state(self.index))
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._th.join(timeout=5.0)
+
+    def summary(self):
+        clk = sorted(r["sclk_mhz"] for r in self.rows if r["sclk_mhz"] is not None)
+        pw = [r["power_w"] for r in self.rows if r["power_w"] is not None]
+        return {"sclk_mhz": [clk[0], clk[len(clk) // 2], clk[-1]] if clk else None,
+                "power_w": [round(sum(pw) / len(pw), 1), max(pw)] if pw else None, "samples": len(self.rows),
+                "what": "sysfs pp_dpm_sclk level / hwmon power1_average sampled every %.0f ms during the timed region: [min, median, max] MHz, [mean, max] W" % (self.period * 1e3)}
+
+
 def pmc_traffic(kernel, slots, N, prec="fp64"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (bench.py cannot
     collect PMC counters itself); None if no summary matches this configuration."""
@@ -171,12 +202,12 @@ def native_multi(args, ndev):
             return ll, info, gpcc_amd.getprobabilities(ll, device=devs[0])
         for _ in range(args.warmup):
             step()
-        st0 = gpu_state(devs[0])
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            ll, info, p = step()
-        elapsed = time.perf_counter() - t0
-        st1 = gpu_state(devs[0])
+        with GpuSampler(devs[0]) as smp:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                ll, info, p = step()
+            elapsed = time.perf_counter() - t0
+        gstate = smp.summary()
         mode = {1: "rccl", 2: "host"}.get(obj.get_option("gather_mode"), "?")
         comp_ms, gather_ms, total_ms = obj.multi_stats()     # of the LAST step: where a scaling loss would come from
     print(json.dumps({
@@ -190,7 +221,7 @@ def native_multi(args, ndev):
                    "parallelism": "ONE process, multi-device handle x%d, 1 all-gather inside libgpcc_hip (%s)" % (N_, mode)},
         "last_step": {"per_device_compute_ms": [round(float(x), 3) for x in comp_ms], "gather_ms": round(gather_ms, 3),
                       "call_ms": round(total_ms, 3)},
-        "clock_mhz": [st0["sclk_mhz"], st1["sclk_mhz"]], "power_w": [st0["power_w"], st1["power_w"]],
+        "clock_mhz": gstate["sclk_mhz"], "power_w": gstate["power_w"], "gpu_state": gstate,
         "info_nonzero": int((info != 0).sum()), "posterior_sum": float(p.sum()), "roofline": None, "cpu_baseline": None}))
 
 
@@ -312,13 +343,15 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    st0 = gpu_state(local) if rank == 0 else None
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    st1 = gpu_state(local) if rank == 0 else None
+    import contextlib
+    smp = GpuSampler(local) if rank == 0 else None
+    with (smp if smp is not None else contextlib.nullcontext()):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+    gstate = smp.summary() if smp is not None else None
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -477,7 +510,7 @@ def main():
                        "grid_total": Gtot, "grid_per_gpu": G, "streams": obj.get_option("workspace_streams"),
                        "slots_per_stream": obj.get_option("workspace_slots"),
                        "parallelism": "grid-sharded x%d, 1 all_gather" % world},
-            "clock_mhz": [st0["sclk_mhz"], st1["sclk_mhz"]], "power_w": [st0["power_w"], st1["power_w"]],
+            "clock_mhz": gstate["sclk_mhz"], "power_w": gstate["power_w"], "gpu_state": gstate,
             "info_nonzero": info_bad, "posterior_sum": psum,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "shared_prefix_mode": shared,
         }
