@@ -35,7 +35,7 @@ def build(force=False, verbose=False):
     # (as ONE translation unit the library took 7.5 minutes to build; the objects are independent, no device linking).
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
-    flags = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed", "-c"]
+    flags = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed", "-Wno-inline-asm", "-c"]
     flags += os.environ.get("GPCC_BUILD_DEFINES", "").split()     # A/B builds (tools/ab_exp.sh: -DGPCC_AB_POLY_EXP into GPCC_HIP_LIB)
     objdir = tempfile.mkdtemp(prefix="gpcc_build_")
     jobs = [(os.path.join(objdir, "gpcc_hip.o"), [os.path.join(CSRC, "gpcc_hip.hip")])]

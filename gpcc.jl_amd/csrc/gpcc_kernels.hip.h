@@ -576,18 +576,49 @@ __device__ __forceinline__ int gpcc_leader_failure(const GpccCtx &c, const GpccG
     return (li < 0 || (li > 0 && li <= c.share_p * GPCC_TILE)) ? li : 0;
 }
 
+// One LDS-DMA piece (1 KiB: 16 bytes per lane) in the SCALAR-ADDRESS form: global address = uniform 64-bit base (an SGPR pair) +
+// one per-lane 32-bit offset + immediate, LDS address in M0 from a scalar.  The builtin, given a per-lane pointer, emits a
+// 64-bit VALU add per piece and moves the LDS address VGPR -> v_readfirstlane -> M0; written out, a piece costs one s_mov and the
+// instruction itself.  (The compiler does not count these loads in its vmcnt bookkeeping: every consumer here already waits with an
+// explicit s_waitcnt vmcnt(N) in front of its barrier.)
+template <int IMM>
+__device__ __forceinline__ void gpcc_dma_piece(const void *gbase, unsigned voff, unsigned lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(gbase), "n"(IMM)
+                 : "memory", "m0");
+}
+__device__ __forceinline__ unsigned gpcc_lds_addr(const void *p)
+{
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) const void *)p);
+}
+// a pointer that IS uniform over the wave, into scalar registers (a no-op where the compiler already keeps it there; where it was
+// derived through vector instructions -- a tile index from sqrtf, say -- the "s" operand of the asm needs it said)
+__device__ __forceinline__ const void *gpcc_uniform_ptr(const void *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (const void *)(((unsigned long long)hi << 32) | lo);
+}
+
 template <typename T>
 __device__ __forceinline__ void gpcc_dma_chunk(const T *gA, const T *gB, T *stage, int wave, int lane)
 {
-    constexpr int PIECE = 1024 / sizeof(T), EP = 16 / sizeof(T), CH = GPCC_CHUNK_BYTES / sizeof(T);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int piece = wave * 2 + i;  // 16 pieces of 1 KiB per 16 KiB chunk, 8 waves x 2
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gA + piece * PIECE + lane * EP),
-                                         (__attribute__((address_space(3))) void *)(stage + piece * PIECE), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gB + piece * PIECE + lane * EP),
-                                         (__attribute__((address_space(3))) void *)(stage + CH + piece * PIECE), 16, 0, 0);
-    }
+    constexpr int PIECE = 1024 / sizeof(T), CH = GPCC_CHUNK_BYTES / sizeof(T);
+    // Round 4: a timing-only build without these instructions showed them to cost 9 % of the update kernel
+    // (tools/timing_variants.sh) -- not the transfers, their ISSUE: per piece a 64-bit VALU address add and a VGPR -> readfirstlane ->
+    // M0 detour, because `tid >> 6` does not tell the compiler that a wave's pieces are uniform.  Now: uniform wave index, scalar
+    // bases (wave's two consecutive pieces = one base + immediate 1024), one per-lane offset.
+    const int uw = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned voff = (unsigned)lane * 16u;
+    const void *pa = gpcc_uniform_ptr(gA + uw * 2 * PIECE), *pb = gpcc_uniform_ptr(gB + uw * 2 * PIECE);
+    const unsigned la = gpcc_lds_addr(stage + uw * 2 * PIECE), lb = gpcc_lds_addr(stage + CH + uw * 2 * PIECE);
+    gpcc_dma_piece<0>(pa, voff, la);        // (the instruction's immediate offset applies to the global AND the LDS address:
+    gpcc_dma_piece<0>(pb, voff, lb);        //  the second piece of a wave is the same M0 with offset:1024)
+    gpcc_dma_piece<1024>(pa, voff, la);
+    gpcc_dma_piece<1024>(pb, voff, lb);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -768,32 +799,58 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
     const T *pa1 = smem + CH + lr * P::KC + (((2 * q + 1) ^ sw) * P::EP);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef GPCC_TIMING_NO_LDSREAD
+    typename P::v16 tim_b0, tim_b1;
+#endif
     for (int ch2 = 0; ch2 < nch; ch2 += 2) {
 #pragma unroll
         for (int st = 0; st < 2; ++st) {  // stage st holds chunk ch2+st (nch is even)
             const int ch = ch2 + st;
+#ifndef GPCC_TIMING_NO_DMA     /* timing-only diagnostic builds (tools/timing_variants.sh): WRONG results, never shipped */
             if (ch + 1 < nch)
                 gpcc_dma_chunk<T>(gI + (long)(ch + 1) * CH, gK + (long)(ch + 1) * CH, smem + (st ^ 1) * 2 * CH, wave, lane);
+#endif
+#ifdef GPCC_TIMING_NO_LDSREAD
+            const int so = 0;
+            typename P::v16 b[2];
+            if (ch == 0) {
+                b[0] = *(const typename P::v16 *)(pb0 + so);
+                b[1] = *(const typename P::v16 *)(pb1 + so);
+            } else {
+                b[0] = tim_b0; b[1] = tim_b1;
+            }
+#else
             const int so = st * 2 * CH;
             typename P::v16 b[2];
             b[0] = *(const typename P::v16 *)(pb0 + so);
             b[1] = *(const typename P::v16 *)(pb1 + so);
+#endif
 #pragma unroll
             for (int h = 0; h < 2; ++h) {  // row-k fragments four at a time (register budget: 128)
                 typename P::v16 a[4][2];
+#ifdef GPCC_TIMING_NO_LDSREAD
+#pragma unroll
+                for (int f = 0; f < 4; ++f) { a[f][0] = b[0] + (typename P::v16)((T)f); a[f][1] = b[1] - (typename P::v16)((T)(f + h)); }
+#else
 #pragma unroll
                 for (int f = 0; f < 4; ++f) {
                     a[f][0] = *(const typename P::v16 *)(pa0 + so + (4 * h + f) * 16 * P::KC);
                     a[f][1] = *(const typename P::v16 *)(pa1 + so + (4 * h + f) * 16 * P::KC);
                 }
+#endif
 #pragma unroll
                 for (int s2 = 0; s2 < P::KSTEPS; ++s2)
 #pragma unroll
                     for (int f = 0; f < 4; ++f)
                         acc[4 * h + f] = P::mfma(a[f][s2 / P::EP][s2 % P::EP], b[s2 / P::EP][s2 % P::EP], acc[4 * h + f]);
             }
+#ifdef GPCC_TIMING_NO_LDSREAD
+            tim_b0 = b[0] * (T)1.0000001; tim_b1 = b[1] * (T)0.9999999;
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef GPCC_TIMING_NO_BARRIER
             __syncthreads();
+#endif
         }
     }
     if (SOLVE) {
@@ -904,7 +961,9 @@ __global__ __launch_bounds__(512, 4) void gpcc_update_solve(GpccCtx c, GpccGroup
     if (m >= g.cnt) return;
     const int I = k + (SOLVE ? 1 : 0) + (g.spread ? (int)blockIdx.x / g.cnt : qq % per);
     const int slot = g.slot0 + m;
+#if !defined(GPCC_TIMING_NO_DMA) && !defined(GPCC_TIMING_NO_LDSREAD) && !defined(GPCC_TIMING_NO_BARRIER)   /* (timing-only builds keep going on garbage) */
     if (c.info[slot] != 0) return;
+#endif
     gpcc_update_solve_job<T, SOLVE>(c, k, I, slot, (T *)smem_raw);
 }
 
