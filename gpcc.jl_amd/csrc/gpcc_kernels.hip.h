@@ -581,13 +581,33 @@ __device__ __forceinline__ int gpcc_leader_failure(const GpccCtx &c, const GpccG
 // 64-bit VALU add per piece and moves the LDS address VGPR -> v_readfirstlane -> M0; written out, a piece costs one s_mov and the
 // instruction itself.  (The compiler does not count these loads in its vmcnt bookkeeping: every consumer here already waits with an
 // explicit s_waitcnt vmcnt(N) in front of its barrier.)
+// two consecutive pieces (2 KiB of one operand, the same M0): one M0 write for both
+__device__ __forceinline__ void gpcc_dma_piece2(const void *gbase, unsigned voff, unsigned lds_addr)
+{
+#ifdef GPCC_AB_DMA_BUILTIN
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)gbase + voff),
+                                     (__attribute__((address_space(3))) void *)(size_t)lds_addr, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)gbase + voff + 1024),
+                                     (__attribute__((address_space(3))) void *)(size_t)(lds_addr + 1024), 16, 0, 0);
+#else
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(gbase)
+                 : "memory", "m0");
+#endif
+}
 template <int IMM>
 __device__ __forceinline__ void gpcc_dma_piece(const void *gbase, unsigned voff, unsigned lds_addr)
 {
+#ifdef GPCC_AB_DMA_BUILTIN   /* A/B builds only (tools/ab_dma.sh): the compiler's form of the same transfer (rounds 1-3) */
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)gbase + voff + IMM),
+                                     (__attribute__((address_space(3))) void *)(size_t)(lds_addr + IMM), 16, 0, 0);
+#else
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
                  :
                  : "s"(lds_addr), "v"(voff), "s"(gbase), "n"(IMM)
                  : "memory", "m0");
+#endif
 }
 __device__ __forceinline__ unsigned gpcc_lds_addr(const void *p)
 {
@@ -603,6 +623,18 @@ __device__ __forceinline__ const void *gpcc_uniform_ptr(const void *p)
     return (const void *)(((unsigned long long)hi << 32) | lo);
 }
 
+// the same with the stage's LDS byte address as a number (hot loops compute it once: a generic -> LDS pointer cast costs a
+// null check and an aperture compare per use)
+template <typename T>
+__device__ __forceinline__ void gpcc_dma_chunk_at(const T *gA, const T *gB, unsigned stage_addr, int wave, int lane)
+{
+    constexpr int PIECE = 1024 / sizeof(T);
+    const int uw = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned voff = (unsigned)lane * 16u;
+    gpcc_dma_piece2(gpcc_uniform_ptr(gA + uw * 2 * PIECE), voff, stage_addr + uw * 2048);
+    gpcc_dma_piece2(gpcc_uniform_ptr(gB + uw * 2 * PIECE), voff, stage_addr + GPCC_CHUNK_BYTES + uw * 2048);
+}
+
 template <typename T>
 __device__ __forceinline__ void gpcc_dma_chunk(const T *gA, const T *gB, T *stage, int wave, int lane)
 {
@@ -615,10 +647,8 @@ __device__ __forceinline__ void gpcc_dma_chunk(const T *gA, const T *gB, T *stag
     const unsigned voff = (unsigned)lane * 16u;
     const void *pa = gpcc_uniform_ptr(gA + uw * 2 * PIECE), *pb = gpcc_uniform_ptr(gB + uw * 2 * PIECE);
     const unsigned la = gpcc_lds_addr(stage + uw * 2 * PIECE), lb = gpcc_lds_addr(stage + CH + uw * 2 * PIECE);
-    gpcc_dma_piece<0>(pa, voff, la);        // (the instruction's immediate offset applies to the global AND the LDS address:
-    gpcc_dma_piece<0>(pb, voff, lb);        //  the second piece of a wave is the same M0 with offset:1024)
-    gpcc_dma_piece<1024>(pa, voff, la);
-    gpcc_dma_piece<1024>(pb, voff, lb);
+    gpcc_dma_piece2(pa, voff, la);          // (the instruction's immediate offset applies to the global AND the LDS address:
+    gpcc_dma_piece2(pb, voff, lb);          //  the second piece of a wave is the same M0 with offset:1024)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -647,7 +677,7 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
     constexpr int CH = GPCC_CHUNK_BYTES / sizeof(T);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *smem = (T *)smem_raw;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and said so)
     const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, q = lane >> 4;
     const int sw = gpcc_sw(lr);
 
@@ -684,12 +714,13 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
 
     T *tiles = (T *)c.tiles + (long)slot * c.slot_stride;
     const T *btiles = shared ? (const T *)c.tiles + (long)g.slot0 * c.slot_stride : tiles;
-    const T *gA = tiles + gpcc_tile_off(I, kcol);
-    const T *gB = btiles + gpcc_tile_off(J, kcol);
+    const T *gA = (const T *)gpcc_uniform_ptr(tiles + gpcc_tile_off(I, kcol));
+    const T *gB = (const T *)gpcc_uniform_ptr(btiles + gpcc_tile_off(J, kcol));
     T *Tt = tiles + gpcc_tile_off(I, J);
     const int nch = P::NCH * ktiles;  // ktiles = k (left-looking), 1 (right-looking), or nt_fact (Schur complement)
 
-    gpcc_dma_chunk<T>(gA, gB, smem, wave, lane);
+    const unsigned smem_addr = gpcc_lds_addr(smem);
+    gpcc_dma_chunk_at<T>(gA, gB, smem_addr, wave, lane);
 
     typename P::acc_t acc[2][4];
 #pragma unroll
@@ -714,7 +745,7 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
         for (int st = 0; st < 2; ++st) {  // stage st holds chunk ch2+st (nch is even)
             const int ch = ch2 + st;
             if (ch + 1 < nch)
-                gpcc_dma_chunk<T>(gA + (long)(ch + 1) * CH, gB + (long)(ch + 1) * CH, smem + (st ^ 1) * 2 * CH, wave, lane);
+                gpcc_dma_chunk_at<T>(gA + (long)(ch + 1) * CH, gB + (long)(ch + 1) * CH, smem_addr + (st ^ 1) * 2 * GPCC_CHUNK_BYTES, wave, lane);
             const int so = st * 2 * CH;
             typename P::v16 a[2][2];
 #pragma unroll
@@ -777,15 +808,17 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
     typedef GpccPrec<T> P;
     constexpr int CH = GPCC_CHUNK_BYTES / sizeof(T);
     constexpr int PIECE = 1024 / sizeof(T), EPB = 16 / sizeof(T);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and said so)
     const int lr = lane & 15, q = lane >> 4;
     const int sw = gpcc_sw(lr);
     T *tiles = (T *)c.tiles + (long)slot * c.slot_stride;
-    const T *gI = tiles + gpcc_tile_off(I, 0);   // tile row I: MFMA B operand (this wave's 16 rows)
-    const T *gK = tiles + gpcc_tile_off(k, 0);   // tile row k: MFMA A operand (all 128 rows)
+    // (uniform over the workgroup, and SAID so: the per-chunk addresses of the LDS-DMA pieces are then scalar arithmetic)
+    const T *gI = (const T *)gpcc_uniform_ptr(tiles + gpcc_tile_off(I, 0));   // tile row I: MFMA B operand (this wave's 16 rows)
+    const T *gK = (const T *)gpcc_uniform_ptr(tiles + gpcc_tile_off(k, 0));   // tile row k: MFMA A operand (all 128 rows)
     T *Tt = tiles + gpcc_tile_off(I, k);
     const int nch = P::NCH * k;
-    if (nch > 0) gpcc_dma_chunk<T>(gI, gK, smem, wave, lane);
+    const unsigned smem_addr = gpcc_lds_addr(smem);
+    if (nch > 0) gpcc_dma_chunk_at<T>(gI, gK, smem_addr, wave, lane);
 
     typename P::acc_t acc[8];   // acc[cf][r'] = -T'^T[c = 16 cf + crow(q, r')][r = 16 wave + lr]
 #pragma unroll
@@ -808,7 +841,7 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
             const int ch = ch2 + st;
 #ifndef GPCC_TIMING_NO_DMA     /* timing-only diagnostic builds (tools/timing_variants.sh): WRONG results, never shipped */
             if (ch + 1 < nch)
-                gpcc_dma_chunk<T>(gI + (long)(ch + 1) * CH, gK + (long)(ch + 1) * CH, smem + (st ^ 1) * 2 * CH, wave, lane);
+                gpcc_dma_chunk_at<T>(gI + (long)(ch + 1) * CH, gK + (long)(ch + 1) * CH, smem_addr + (st ^ 1) * 2 * GPCC_CHUNK_BYTES, wave, lane);
 #endif
 #ifdef GPCC_TIMING_NO_LDSREAD
             const int so = 0;
@@ -871,9 +904,8 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
 #pragma unroll
         for (int ch = 0; ch < P::NCH; ++ch) {
             const int r0x = 16 * FPC * ch, npiece = (GPCC_TILE - r0x) * P::KC / PIECE;   // 1 KiB pieces of this chunk's lower rows
-            for (int pc = wave; pc < npiece; pc += 8)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gX + (long)ch * CH + r0x * P::KC + pc * PIECE + lane * EPB),
-                                                 (__attribute__((address_space(3))) void *)(smem + xoff[ch] + pc * PIECE), 16, 0, 0);
+            for (int pc = __builtin_amdgcn_readfirstlane(wave); pc < npiece; pc += 8)
+                gpcc_dma_piece<0>(gpcc_uniform_ptr(gX + (long)ch * CH + r0x * P::KC + pc * PIECE), (unsigned)lane * 16u, gpcc_lds_addr(smem + xoff[ch] + pc * PIECE));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -981,7 +1013,7 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_trsm(GpccCtx c, GpccGroup g
     constexpr int CH = GPCC_CHUNK_BYTES / sizeof(T);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *smem = (T *)smem_raw;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and said so)
     const int lr = lane & 15, q = lane >> 4;
     const int sw = gpcc_sw(lr);
 
@@ -1004,8 +1036,8 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_trsm(GpccCtx c, GpccGroup g
 
     T *tiles = (T *)c.tiles + (long)slot * c.slot_stride;
     T *Tt = tiles + gpcc_tile_off(I, k);
-    const T *gA = Tt;                                                // the chunks of T(I,k), overwritten at the end
-    const T *gB = (const T *)c.linv + gpcc_linv_off(c, lslot, k);  // inv(L_kk): rows = output column, k = j
+    const T *gA = (const T *)gpcc_uniform_ptr(Tt);                                                // the chunks of T(I,k), overwritten at the end
+    const T *gB = (const T *)gpcc_uniform_ptr((const T *)c.linv + gpcc_linv_off(c, lslot, k));  // inv(L_kk): rows = output column, k = j
 
     gpcc_dma_chunk<T>(gA, gB, smem, wave, lane);
     typename P::acc_t acc[8];
@@ -1096,7 +1128,7 @@ __global__ __launch_bounds__(512) void gpcc_panel_trsm_rows(GpccCtx c, GpccGroup
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *smem = (T *)smem_raw;
     __shared__ double sred[8][16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and said so)
     const int lr = lane & 15, q = lane >> 4, sw = gpcc_sw(lr);
     const int rh = wave & 1, cp = wave >> 1, f0 = cp, f1 = 7 - cp;
     const int m = (int)blockIdx.x % g.cnt, rest = (int)blockIdx.x / g.cnt;
@@ -1108,15 +1140,12 @@ __global__ __launch_bounds__(512) void gpcc_panel_trsm_rows(GpccCtx c, GpccGroup
     const T *gB = (const T *)c.linv + gpcc_linv_off(c, slot, k);
     auto dma = [&](int ch, int st) {   // three 1 KiB pieces per wave and chunk (the A pieces of waves 4-7 repeat those of 0-3)
         T *stage = smem + st * STG;
-        const int pa = wave & 3;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gA + (long)ch * CH + pa * PIECE + lane * EPB),
-                                         (__attribute__((address_space(3))) void *)(stage + pa * PIECE), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int pb = wave * 2 + i;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gB + (long)ch * CH + pb * PIECE + lane * EPB),
-                                             (__attribute__((address_space(3))) void *)(stage + AQ + pb * PIECE), 16, 0, 0);
-        }
+        const int uw = __builtin_amdgcn_readfirstlane(wave), pa = uw & 3;
+        const unsigned voff = (unsigned)lane * 16u;
+        gpcc_dma_piece<0>(gpcc_uniform_ptr(gA + (long)ch * CH + pa * PIECE), voff, gpcc_lds_addr(stage + pa * PIECE));
+        const void *pbase = gpcc_uniform_ptr(gB + (long)ch * CH + uw * 2 * PIECE);
+        const unsigned lb = gpcc_lds_addr(stage + AQ + uw * 2 * PIECE);
+        gpcc_dma_piece2(pbase, voff, lb);
     };
 #pragma unroll
     for (int pc = 0; pc < STAGES - 1 && pc < P::NCH; ++pc) dma(pc, pc);
@@ -1674,12 +1703,10 @@ __device__ __forceinline__ void gpcc_syrk_lower_wave(const T *gRow, int nch, T *
     const int lr = lane & 15, q = lane >> 4, sw = gpcc_sw(lr);
     auto dma = [&](int ch) {   // two 1 KiB pieces per wave and chunk
         T *stage = smem + (ch % STAGES) * CH;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int pc = wave * 2 + i;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gRow + (long)ch * CH + pc * PIECE + lane * EPB),
-                                             (__attribute__((address_space(3))) void *)(stage + pc * PIECE), 16, 0, 0);
-        }
+        const int uw = __builtin_amdgcn_readfirstlane(wave);
+        const void *pbase = gpcc_uniform_ptr(gRow + (long)ch * CH + uw * 2 * PIECE);
+        const unsigned la = gpcc_lds_addr(stage + uw * 2 * PIECE), voff = (unsigned)lane * 16u;
+        gpcc_dma_piece2(pbase, voff, la);
     };
     typename P::acc_t acc[NA + NB];
 #pragma unroll
@@ -1748,7 +1775,7 @@ __global__ __launch_bounds__(512) void gpcc_small_step(GpccCtx c, GpccGroup g, i
     constexpr int CH = GPCC_CHUNK_BYTES / sizeof(T);
     extern __shared__ __attribute__((aligned(16))) double smem_d[];
     T *smem = (T *)smem_d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and said so)
     const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, q = lane >> 4;
     const int sw = gpcc_sw(lr);
     const int m = (int)blockIdx.x % g.cnt, j = (int)blockIdx.x / g.cnt;   // job j of evaluation m; j = 0 is tile (k+1,k+1)
@@ -1762,7 +1789,7 @@ __global__ __launch_bounds__(512) void gpcc_small_step(GpccCtx c, GpccGroup g, i
     while ((a + 1) * (a + 2) / 2 <= j) ++a;
     const int I = k + 1 + a, J = k + 1 + (j - a * (a + 1) / 2);
     T *tiles = (T *)c.tiles + (long)slot * c.slot_stride;
-    const T *gA = tiles + gpcc_tile_off(I, k), *gB = tiles + gpcc_tile_off(J, k);
+    const T *gA = (const T *)gpcc_uniform_ptr(tiles + gpcc_tile_off(I, k)), *gB = (const T *)gpcc_uniform_ptr(tiles + gpcc_tile_off(J, k));
     T *Tt = tiles + gpcc_tile_off(I, J);
     if (j == 0) {   // tile (k+1,k+1): lower triangle only (both operands are tile (k+1,k)), then straight on into the diagonal step
         switch (__builtin_amdgcn_readfirstlane(wave)) {
@@ -1845,7 +1872,7 @@ __global__ __launch_bounds__(512) void gpcc_syrk_diag(GpccCtx c, GpccGroup g, in
 {
     extern __shared__ __attribute__((aligned(16))) double smem_d[];
     T *smem = (T *)smem_d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and said so)
     const int m = blockIdx.x, slot = g.slot0 + m;
     if (c.info[slot] == 0) {
         const T *tiles = (const T *)c.tiles + (long)slot * c.slot_stride;
