@@ -818,7 +818,13 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
     T *Tt = tiles + gpcc_tile_off(I, k);
     const int nch = P::NCH * k;
     const unsigned smem_addr = gpcc_lds_addr(smem);
+    // (Measured and dropped in round 4: the B operand -- this wave's own 16 rows of tile row I -- loaded straight into registers
+    // instead of through LDS: +0.5 % with hand-written global loads, which the compiler cannot track -- it copies or spills the
+    // destination registers before the data has landed (fp32 and gpcc_step returned garbage now and then) --, and with loads it can
+    // track it inserts its own s_waitcnt that counts the untracked LDS-DMA pieces as older loads and stalls every chunk.)
     if (nch > 0) gpcc_dma_chunk_at<T>(gI, gK, smem_addr, wave, lane);
+    const T *pb0 = smem + (wave * 16 + lr) * P::KC + (((2 * q) ^ sw) * P::EP);        // stage: [row I chunk | row k chunk]
+    const T *pb1 = smem + (wave * 16 + lr) * P::KC + (((2 * q + 1) ^ sw) * P::EP);
 
     typename P::acc_t acc[8];   // acc[cf][r'] = -T'^T[c = 16 cf + crow(q, r')][r = 16 wave + lr]
 #pragma unroll
@@ -826,60 +832,36 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[cf][r] = -Tt[gpcc_elem_off<T>(wave * 16 + lr, cf * 16 + P::crow(q, r))];
 
-    const T *pb0 = smem + (wave * 16 + lr) * P::KC + (((2 * q) ^ sw) * P::EP);        // stage: [row I chunk | row k chunk]
-    const T *pb1 = smem + (wave * 16 + lr) * P::KC + (((2 * q + 1) ^ sw) * P::EP);
     const T *pa0 = smem + CH + lr * P::KC + (((2 * q) ^ sw) * P::EP);
     const T *pa1 = smem + CH + lr * P::KC + (((2 * q + 1) ^ sw) * P::EP);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#ifdef GPCC_TIMING_NO_LDSREAD
-    typename P::v16 tim_b0, tim_b1;
-#endif
     for (int ch2 = 0; ch2 < nch; ch2 += 2) {
 #pragma unroll
         for (int st = 0; st < 2; ++st) {  // stage st holds chunk ch2+st (nch is even)
             const int ch = ch2 + st;
+            const int so = st * 2 * CH;
 #ifndef GPCC_TIMING_NO_DMA     /* timing-only diagnostic builds (tools/timing_variants.sh): WRONG results, never shipped */
             if (ch + 1 < nch)
                 gpcc_dma_chunk_at<T>(gI + (long)(ch + 1) * CH, gK + (long)(ch + 1) * CH, smem_addr + (st ^ 1) * 2 * GPCC_CHUNK_BYTES, wave, lane);
 #endif
-#ifdef GPCC_TIMING_NO_LDSREAD
-            const int so = 0;
-            typename P::v16 b[2];
-            if (ch == 0) {
-                b[0] = *(const typename P::v16 *)(pb0 + so);
-                b[1] = *(const typename P::v16 *)(pb1 + so);
-            } else {
-                b[0] = tim_b0; b[1] = tim_b1;
-            }
-#else
-            const int so = st * 2 * CH;
             typename P::v16 b[2];
             b[0] = *(const typename P::v16 *)(pb0 + so);
             b[1] = *(const typename P::v16 *)(pb1 + so);
-#endif
 #pragma unroll
             for (int h = 0; h < 2; ++h) {  // row-k fragments four at a time (register budget: 128)
                 typename P::v16 a[4][2];
-#ifdef GPCC_TIMING_NO_LDSREAD
-#pragma unroll
-                for (int f = 0; f < 4; ++f) { a[f][0] = b[0] + (typename P::v16)((T)f); a[f][1] = b[1] - (typename P::v16)((T)(f + h)); }
-#else
 #pragma unroll
                 for (int f = 0; f < 4; ++f) {
                     a[f][0] = *(const typename P::v16 *)(pa0 + so + (4 * h + f) * 16 * P::KC);
                     a[f][1] = *(const typename P::v16 *)(pa1 + so + (4 * h + f) * 16 * P::KC);
                 }
-#endif
 #pragma unroll
                 for (int s2 = 0; s2 < P::KSTEPS; ++s2)
 #pragma unroll
                     for (int f = 0; f < 4; ++f)
                         acc[4 * h + f] = P::mfma(a[f][s2 / P::EP][s2 % P::EP], b[s2 / P::EP][s2 % P::EP], acc[4 * h + f]);
             }
-#ifdef GPCC_TIMING_NO_LDSREAD
-            tim_b0 = b[0] * (T)1.0000001; tim_b1 = b[1] * (T)0.9999999;
-#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifndef GPCC_TIMING_NO_BARRIER
             __syncthreads();
