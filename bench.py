@@ -64,9 +64,20 @@ def gpu_state(index=0):
     import glob
     out = {"sclk_mhz": None, "power_w": None}
     try:
+        path = None
+        try:    # the HIP device's own PCI function (the box may expose more cards in sysfs than HIP devices, in another order)
+            import torch
+            pr = torch.cuda.get_device_properties(index)
+            bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            cand = "/sys/bus/pci/devices/%s/pp_dpm_sclk" % bdf
+            if os.path.exists(cand):
+                path = cand
+        except Exception:
+            path = None
         cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
-        if cards:
+        if path is None and cards:
             path = cards[min(index, len(cards) - 1)]
+        if path:
             for line in open(path):
                 if "*" in line:
                     out["sclk_mhz"] = int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
@@ -100,14 +111,16 @@ def small_executed_ops(N, kernel):
     """Double-precision pipe work one small-N evaluation EXECUTES (flops; an fma = 2), by source -- the count behind DESIGN.md 4.10's
     cycle budget.  NB = blocks of the matrix bordered by the right-hand side.  MFMA: row J of the row-wise Cholesky applies J
     finished rows to NB - J blocks and multiplies NB - J - 1 blocks by -inv(L_D): 4 v_mfma_f64_16x16x4_f64 = 8192 flops per block
-    product.  Elements: NB(NB+1)/2 blocks x 256 elements x (exp: 19 ops, 16 of them fma = 35 flops; + distance, scale, Matern
-    polynomial, amplitudes, + Sobs / + B: ~8 flops).  Diagonal step: NB x 16 pivots x (16 x 2 lanes-wide fma rows ~ 2 x 16 x 16 / 2
-    useful flops, issued as 64-lane instructions: 16 pivots x ~(15 fma + 12 chain ops) x 64 lanes)."""
+    product.  Elements (round 4, separable form): NB(NB+1)/2 blocks x 256 elements x (2 mul + min + distance + scale + Matern
+    polynomial + Sobs / B: ~10 flops) plus 2 exponentials per point in the set-up (~70 flops each); rbf keeps the direct form (exp:
+    19 ops, 16 of them fma = 35 flops, + ~9).  Diagonal step: NB x 16 pivots x ~(15 fma + 12 chain ops), issued as 64-lane
+    instructions."""
     NB = (N + 1 + 15) // 16
     mfma_blocks = sum(J * (NB - J) + (NB - J - 1) for J in range(NB))
     poly = {"OU": 0, "rbf": 1, "matern32": 2, "matern52": 4}.get(kernel, 2)
+    per_elem = (35.0 + 8.0 + poly) if kernel == "rbf" else (8.0 + poly)
     return {"mfma": mfma_blocks * 8192.0,
-            "element_code": NB * (NB + 1) / 2 * 256 * (35.0 + 8.0 + poly),
+            "element_code": NB * (NB + 1) / 2 * 256 * per_elem + (0.0 if kernel == "rbf" else 2.0 * N * 70.0),
             "pivot_steps_16x16": NB * 16 * (2.0 * 15 + 12.0) * 64}
 
 
