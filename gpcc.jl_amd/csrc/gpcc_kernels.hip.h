@@ -824,6 +824,9 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
     // instead of through LDS: +0.5 % with hand-written global loads, which the compiler cannot track -- it copies or spills the
     // destination registers before the data has landed (fp32 and gpcc_step returned garbage now and then) --, and with loads it can
     // track it inserts its own s_waitcnt that counts the untracked LDS-DMA pieces as older loads and stalls every chunk.)
+    // (Measured and dropped in round 4: ONE barrier per TWO chunks -- the B operand is a wave's own rows and needs no barrier, the A
+    // operand in a ring of four stages filled a pair ahead, 64 MFMAs per wave between barriers: correct, and not a percent faster
+    // (fp32 -1 %).  What the timing-only "no barrier" build gains is waves running free of each other, not the barriers' own cost.)
     if (nch > 0) gpcc_dma_chunk_at<T>(gI, gK, smem_addr, wave, lane);
     const T *pb0 = smem + (wave * 16 + lr) * P::KC + (((2 * q) ^ sw) * P::EP);        // stage: [row I chunk | row k chunk]
     const T *pb1 = smem + (wave * 16 + lr) * P::KC + (((2 * q + 1) ^ sw) * P::EP);
@@ -846,7 +849,6 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
 #ifndef GPCC_TIMING_NO_DMA     /* timing-only diagnostic builds (tools/timing_variants.sh): WRONG results, never shipped */
             if (ch + 1 < nch)
                 gpcc_dma_chunk_at<T>(gI + (long)(ch + 1) * CH, gK + (long)(ch + 1) * CH, smem_addr + (st ^ 1) * 2 * GPCC_CHUNK_BYTES, wave, lane);
-#endif
             typename P::v16 b[2];
             b[0] = *(const typename P::v16 *)(pb0 + so);
             b[1] = *(const typename P::v16 *)(pb1 + so);
@@ -870,6 +872,7 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
 #endif
         }
     }
+#endif
     if (SOLVE) {
         // ---- lower blocks of X = inv(L_kk) -> LDS, packed chunk by chunk: chunk ch2 of the tile holds columns KC ch2 .. of all
         // 128 rows; rows above the chunk's first column block are zero and skipped.  Block (i, cf) is then read at
