@@ -125,6 +125,8 @@ struct gpcc_handle_s {
     int fused_solve_min = 112;   // ... from this group size on (below it the diagonal tile's serial K-loop on ONE CU per evaluation costs
                                  // more than the fused solve saves: measured crossover 96-128 evaluations at N = 1024 and N = 4096)
     int fused_solve = 1;     // option "fused_solve": left-looking groups run gpcc_syrk_diag + gpcc_update_solve (2 launches per step)
+    int fold_assembly = 1;   // option "fold_assembly": fused left-looking fp64 groups of the exponential kernels do not assemble the off-diagonal
+                             // tiles that lie inside one band pair; gpcc_update_solve evaluates them into its accumulators (GpccCtx::fold)
     int step_fused = 0;      // option "step_fused": ... as ONE launch per step (gpcc_step: the diagonal step of column k+1 inside the update
                              // launch of column k, on half a CU's LDS); 0 = the two launches of round 2
     int diag_blocks = 0;     // option "diag_blocks": the three-kernel path's diagonal step on the packed block image (gpcc_diag_factor2,
@@ -160,6 +162,8 @@ struct gpcc_handle_s {
     int *d_info = nullptr;
     double *d_kdiag = nullptr, *d_cond = nullptr;   // fp32 mode: diag(K) as assembled, pivot-ratio sums (GpccCtx)
     double *d_gpart = nullptr;                      // fp32 mode: per-tile partials of X' K0 X (refinement)
+    double *d_sep = nullptr, *d_seps = nullptr;     // separable factors of the points, the distance scale (GpccCtx::sep, ::seps)
+    int *d_sepflag = nullptr;                       // per-tile-row flags (GpccCtx::sepflag)
     int fp32_refine = 1;                            // option "fp32_refine": 0 = no refinement of the quadratic forms
     int fp32_assemble = 1;                          // option "fp32_assemble": fp32 tiles inside one band pair are EVALUATED in fp32 as well (0: in fp64,
                                                     // rounded once).  +3.6 % at N = 4096; soak and adversarial search unchanged (worst 2.9e-5 / 3.4e-4):
@@ -415,8 +419,10 @@ static void free_workspace(gpcc_handle_t h)
 {
     hipFree(h->d_tiles); hipFree(h->d_linv); hipFree(h->d_z); hipFree(h->d_w);
     hipFree(h->d_logdet); hipFree(h->d_quad); hipFree(h->d_info); hipFree(h->d_kdiag); hipFree(h->d_cond); hipFree(h->d_gpart);
+    hipFree(h->d_sep); hipFree(h->d_seps); hipFree(h->d_sepflag);
     h->d_tiles = h->d_linv = h->d_z = h->d_w = h->d_logdet = h->d_quad = h->d_kdiag = h->d_cond = h->d_gpart = nullptr;
-    h->d_info = nullptr;
+    h->d_sep = h->d_seps = nullptr;
+    h->d_info = h->d_sepflag = nullptr;
     for (int s = 0; s < GPCC_MAX_STREAMS; ++s) {
         if (h->str[s]) { hipStreamDestroy(h->str[s]); h->str[s] = nullptr; }
         if (h->ev_done[s]) { hipEventDestroy(h->ev_done[s]); h->ev_done[s] = nullptr; }
@@ -471,6 +477,8 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->update_t = (int)v;
     } else if (!strcmp(key, "fused_solve")) {
         h->fused_solve = v != 0;
+    } else if (!strcmp(key, "fold_assembly")) {
+        h->fold_assembly = v != 0;
     } else if (!strcmp(key, "step_fused")) {
         h->step_fused = v != 0;
     } else if (!strcmp(key, "diag_blocks")) {
@@ -544,6 +552,7 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "precision")) return h->precision;
     if (!strcmp(key, "fused_solve")) return h->fused_solve;
     if (!strcmp(key, "fused_solve_min")) return h->fused_solve_min;
+    if (!strcmp(key, "fold_assembly")) return h->fold_assembly;
     if (!strcmp(key, "step_fused")) return h->step_fused;
     if (!strcmp(key, "diag_blocks")) return h->diag_blocks;
     if (!strcmp(key, "small_n")) return h->small_n;
@@ -638,6 +647,9 @@ static int ensure_workspace(gpcc_handle_t h)
         if (e == hipSuccess) e = hipMalloc(&h->d_logdet, sizeof(double) * slots);
         if (e == hipSuccess) e = hipMalloc(&h->d_quad, sizeof(double) * GPCC_MAXRHS * GPCC_MAXRHS * slots);
         if (e == hipSuccess) e = hipMalloc(&h->d_info, sizeof(int) * slots);
+        if (e == hipSuccess) e = hipMalloc(&h->d_sep, sizeof(double) * 3 * h->Np * slots);
+        if (e == hipSuccess) e = hipMalloc(&h->d_seps, sizeof(double) * slots);
+        if (e == hipSuccess) e = hipMalloc(&h->d_sepflag, sizeof(int) * h->nt * slots);
         if (e == hipSuccess && h->precision == GPCC_PRECISION_FP32) {
             e = hipMalloc(&h->d_kdiag, sizeof(double) * h->Np * slots);
             if (e == hipSuccess) e = hipMalloc(&h->d_cond, sizeof(double) * 2 * slots);
@@ -682,6 +694,7 @@ static GpccCtx make_ctx(gpcc_handle_t h)
     c.linv_keep = (h->precision == GPCC_PRECISION_FP32) ? 1 : 2;
     c.t = h->d_t; c.sig2 = h->d_sig2; c.resid = h->d_resid; c.band = h->d_band; c.yv = h->d_yv;
     c.tmid = h->tmid;
+    c.sep = h->d_sep; c.seps = h->d_seps; c.sepflag = h->d_sepflag; c.fold = 0;
     for (int l = 0; l < GPCC_MAXL; ++l) c.sigma_b[l] = (l < h->L) ? h->sigma_b[l] : 0.0;
     c.slot_stride = h->slot_stride;
     c.L = h->L; c.N = h->N; c.Np = h->Np; c.nt = h->nt; c.kernel_id = h->kernel_id; c.marginalise_b = h->mb;
@@ -724,10 +737,30 @@ static void launch_assemble(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &
 
 static int enqueue_factor(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s, bool f32, int concurrent);
 
-static int enqueue_group(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s, bool factor = true,
+// the group runs left-looking with the panel solve inside the update (gpcc_syrk_diag + gpcc_update_solve)
+static bool takes_fused_solve(gpcc_handle_t h, const GpccCtx &c, int cnt)
+{
+    const bool right = (cnt <= h->right_looking_max) && (c.nt_fact == c.nt) && !c.share_p;
+    return !right && !c.share_p && c.nt_fact == c.nt && h->fused_solve && cnt >= h->fused_solve_min && !c.store_l;
+}
+
+static int enqueue_group(gpcc_handle_t h, const GpccCtx &c_in, const GpccGroup &g, hipStream_t s, bool factor = true,
                          bool ext = false, int f32 = -1, int concurrent = 1)
 {
     const bool single = (f32 < 0) ? (h->precision == GPCC_PRECISION_FP32) : (f32 != 0);
+    GpccCtx c = c_in;
+    // fold: on the fused path every off-diagonal tile (I,k) is read exactly once, by the job that updates and solves it -- which can
+    // evaluate the elements itself (gpcc_update_solve); only what the flags of gpcc_sep_points exclude is still assembled
+    c.fold = (factor && !ext && !single && h->fold_assembly && c.kernel_id != 1 && c.sep && c.nt > 1 && takes_fused_solve(h, c, g.cnt)) ? 1 : 0;
+    if (c.fold) {
+        ProfScope p(h, GPCC_PROF_ASSEMBLE, s);
+        dim3 grid(c.nt, g.cnt);
+        switch (c.kernel_id) {
+        case 0: gpcc_sep_points<0><<<grid, GPCC_TILE, 0, s>>>(c, g); break;
+        case 2: gpcc_sep_points<2><<<grid, GPCC_TILE, 0, s>>>(c, g); break;
+        default: gpcc_sep_points<3><<<grid, GPCC_TILE, 0, s>>>(c, g); break;
+        }
+    }
     launch_assemble(h, c, g, s, ext, single);
     if (!factor) return 0;
     int rc = enqueue_factor(h, c, g, s, single, concurrent);
@@ -786,7 +819,7 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
         }
         return;
     }
-    if (!right && !p && c.nt_fact == c.nt && h->fused_solve && g.cnt >= h->fused_solve_min && !c.store_l) {
+    if (takes_fused_solve(h, c, g.cnt)) {
         // left-looking, the panel solve inside the update (gpcc_update_solve): per step the diagonal tile first
         // (gpcc_syrk_diag: lower-triangle update + diagonal step in one workgroup per evaluation), then the rest of column k
         if (h->step_fused && c.nrhs <= GPCC_DB_MAXRHS) {
@@ -1291,6 +1324,7 @@ static int run_augmented(gpcc_handle_t h, const double *delays, const double *al
     c.tiles = a.d_ws; c.linv = a.d_ws + stride; c.z = a.d_ws + stride + GPCC_TILE_ELEMS; c.w = c.z + Npa;
     c.logdet = c.w + Npa; c.gram = c.logdet + 1; c.info = a.d_info;
     c.kdiag = nullptr; c.cond = nullptr; c.gpart = nullptr; c.linv_keep = 0;
+    c.sep = nullptr; c.seps = nullptr; c.sepflag = nullptr;   // (sized for the handle's own N: never folded here)
     c.slot_stride = stride; c.Np = Npa; c.nt = nta; c.nt_fact = h->nt; c.marginalise_b = marginalise_b;
     c.nrhs = 1; c.woodbury = 0;   // the dense utilities always run the literal fp64 model
     c.store_l = 1;

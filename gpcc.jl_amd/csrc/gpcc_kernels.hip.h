@@ -76,6 +76,11 @@ struct GpccCtx {
     double *cond;    // slots x 2  : sum_i K_ii / d_i and max_i K_ii / d_i over the pivots d_i (fp32 mode only) -- the
                      //              a-posteriori conditioning measure behind the fp64 re-evaluation, DESIGN.md 4.7
     double tmid;     // midpoint of the observation times: centre of the separable-exponential form (gpcc_sep_point)
+    double *sep;     // slots x 3 x Np : shifted times u, separable factors A, B of every point (gpcc_sep_points; fold only)
+    double *seps;    // slots          : the kernel's scale of the distance, s (gpcc_kernel_scale)
+    int *sepflag;    // slots x nt     : tile row I lies inside ONE band b and all its points are in the separable range: b + 1; else 0
+    int fold;        // 1: the off-diagonal tiles whose two tile rows are flagged are NOT assembled -- gpcc_update_solve evaluates their
+                     //    elements into its accumulators (fused left-looking groups, fp64, the exponential kernels)
     const double *t, *sig2, *resid;  // Np (padding: 0)
     const double *yv;                // Np: raw fluxes (only read by explicit 'Y' rows, see band codes)
     const int *band;                 // Np: >= 0 band of a real point; -1 identity padding;
@@ -371,6 +376,49 @@ __device__ __forceinline__ double gpcc_sep_eval(double ui, double uj, double Ai,
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool diag_tile(int I, int J) { return I == J; }
 
+// gpcc_sep_points (fold only): u, A, B of every point of `cnt` evaluations, the scale s and the per-tile-row flags of GpccCtx -- the
+// SAME values gpcc_assemble_tiles stages per tile (same functions, same arguments), computed once per evaluation.
+// grid (nt, cnt), block 128.
+template <int KID>
+__global__ __launch_bounds__(GPCC_TILE) void gpcc_sep_points(GpccCtx c, GpccGroup g)
+{
+    const int I = blockIdx.x, m = blockIdx.y, slot = g.slot0 + m, r = threadIdx.x;
+    const double *delays = g.delays + (long)(g.first + m) * c.L;
+    const double *alpha = g.alpha + (long)(g.first + m) * c.L;
+    const GpccKernelConst kc = gpcc_kernel_const<KID>(g.rho[g.first + m]);
+    const double s = gpcc_kernel_scale<KID>(kc);
+    const int gi = I * GPCC_TILE + r;
+    const int b = c.band[gi], b0 = c.band[I * GPCC_TILE];
+    const double u_ = (b >= 0) ? c.t[gi] - delays[b] : 0.0;
+    const double a_ = (b >= 0) ? alpha[b] : 0.0;
+    double A_ = 0.0, B_ = 0.0;
+    const bool ok = gpcc_sep_point(u_, c.tmid, s, a_, A_, B_);
+    double *sp = c.sep + (long)slot * 3 * c.Np;
+    sp[gi] = u_;
+    sp[c.Np + gi] = A_;
+    sp[2 * (long)c.Np + gi] = B_;
+    const int all = __syncthreads_and((ok && b >= 0 && b == b0) ? 1 : 0);
+    if (r == 0) {
+        c.sepflag[(long)slot * c.nt + I] = all ? b0 + 1 : 0;
+        if (I == 0) c.seps[slot] = s;
+    }
+}
+
+// the accumulators of tile (I,k) from the separable factors (gpcc_update_solve, fold): acc[cf][r'] = -K[row][16 cf + crow(q, r')],
+// the element exactly as gpcc_assemble_tiles' select-free path forms it (same expression, same operand order)
+template <int KID, typename P, typename ACC>
+__device__ __forceinline__ void gpcc_fold_init(ACC (&acc)[8], double ui, double Ai, double Bi, const double *cu, const double *cA,
+                                               const double *cB, double s, double bt, int q)
+{
+#pragma unroll
+    for (int cf = 0; cf < 8; ++cf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = cf * 16 + P::crow(q, r);
+            acc[cf][r] = -(gpcc_sep_eval<KID>(ui, cu[j], Ai, Bi, cA[j], cB[j], s) + bt);
+        }
+}
+
 template <int KID, bool EXT, typename T>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 4) void gpcc_assemble_tiles(GpccCtx c, GpccGroup g)
 {
@@ -380,6 +428,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 4) void gpcc_assemble_til
     const int m = blockIdx.y, slot = g.slot0 + m, tid = threadIdx.x;
     const int first_row = (c.share_p && m > 0) ? c.share_p : 0;   // followers of a shared prefix skip the leader's rows
     if (I < first_row) return;
+    // fold: this tile is never read from memory -- gpcc_update_solve evaluates it into its accumulators (flags: gpcc_sep_points)
+    if (KID != 1 && c.fold && I != J && c.sepflag[(long)slot * c.nt + I] != 0 && c.sepflag[(long)slot * c.nt + J] != 0) return;
     const double *delays = g.delays + (long)(g.first + m) * c.L;
     const double *alpha = g.alpha + (long)(g.first + m) * c.L;
     const GpccKernelConst kc = gpcc_kernel_const<KID>(g.rho[g.first + m]);
@@ -832,10 +882,34 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
     const T *pb1 = smem + (wave * 16 + lr) * P::KC + (((2 * q + 1) ^ sw) * P::EP);
 
     typename P::acc_t acc[8];   // acc[cf][r'] = -T'^T[c = 16 cf + crow(q, r')][r = 16 wave + lr]
+    // fold (round 4): a tile inside one band pair whose points are in the separable range was never assembled -- its elements are
+    // evaluated here, from 2 x 128 points' factors (3 KiB, cached) instead of a 128 KiB tile written and read back; ~7 double-precision
+    // operations per element = 0.5 % of the job's matrix work at the mean k, under the first chunk's LDS-DMA
+    int fI = 0, fk = 0;
+    if (SOLVE && sizeof(T) == 8 && c.fold) {
+        fI = __builtin_amdgcn_readfirstlane(c.sepflag[(long)slot * c.nt + I]);
+        fk = __builtin_amdgcn_readfirstlane(c.sepflag[(long)slot * c.nt + k]);
+    }
+    if (SOLVE && sizeof(T) == 8 && fI != 0 && fk != 0) {
+        const double *sp = c.sep + (long)slot * 3 * c.Np;
+        const double s = c.seps[slot];
+        double bt = 0.0;
+        if (c.marginalise_b != 0 && !c.woodbury && fI == fk) {
 #pragma unroll
-    for (int cf = 0; cf < 8; ++cf)
+            for (int l = 0; l < GPCC_MAXL; ++l) bt = (fI - 1 == l) ? c.sigma_b[l] : bt;   // (no dynamic index into the kernel argument)
+        }
+        const int ri = I * GPCC_TILE + wave * 16 + lr;
+        const double ui = sp[ri], Ai = sp[c.Np + ri], Bi = sp[2 * (long)c.Np + ri];
+        const double *cu = sp + k * GPCC_TILE, *cA = cu + c.Np, *cB = cA + c.Np;
+        if (c.kernel_id == 0) gpcc_fold_init<0, P>(acc, ui, Ai, Bi, cu, cA, cB, s, bt, q);
+        else if (c.kernel_id == 2) gpcc_fold_init<2, P>(acc, ui, Ai, Bi, cu, cA, cB, s, bt, q);
+        else gpcc_fold_init<3, P>(acc, ui, Ai, Bi, cu, cA, cB, s, bt, q);
+    } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[cf][r] = -Tt[gpcc_elem_off<T>(wave * 16 + lr, cf * 16 + P::crow(q, r))];
+        for (int cf = 0; cf < 8; ++cf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[cf][r] = -Tt[gpcc_elem_off<T>(wave * 16 + lr, cf * 16 + P::crow(q, r))];
+    }
 
     const T *pa0 = smem + CH + lr * P::KC + (((2 * q) ^ sw) * P::EP);
     const T *pa1 = smem + CH + lr * P::KC + (((2 * q + 1) ^ sw) * P::EP);

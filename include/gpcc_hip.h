@@ -101,6 +101,9 @@ int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms
  * most 4 right-hand sides, i.e. fp32 handles with more than 3 bands keep the round-2 kernels).  Both were built to let the
  * diagonal step run beside update workgroups and MEASURED not to pay (the fp64 matrix pipe bounds the step, and the pivot chain
  * runs 2-3x slower beside MFMA-saturating waves than alone on a CU: DESIGN.md 4.2e), hence off,
+ * "fold_assembly" (round 4; 1 = default: fp64 groups on the fused_solve path with OU / Matern kernels do not write the off-diagonal
+ * tiles of delayedCovariance that lie inside one band pair -- the update kernel evaluates those elements into its accumulators, the
+ * same bits gpcc_model_matrix returns; 0 = every tile is assembled first, as in rounds 1-3),
  * "shared_prefix" (0 off; 1 = default: gpcc_loglik_batch detects a
  * batch whose evaluations all have the same band-1 amplitude, delay and rho -- a fixed-hyper-parameter delay
  * sweep, README.md:172-174 -- and then factorises the tile rows wholly inside band 1 once per group instead of

@@ -1,0 +1,97 @@
+"""Round 4: the assembly folded into the update (option fold_assembly, GpccCtx::fold).  On the fused left-looking path every
+off-diagonal tile (I,k) is read exactly once, by the job that updates and solves it; with the fold that job evaluates the tile's
+elements itself -- from the separable factors gpcc_sep_points computes once per evaluation -- instead of reading what
+gpcc_assemble_tiles wrote.  The element is formed by the SAME expression in both places (gpcc_sep_eval + the B term), so the
+log-likelihoods must agree BITWISE with fold_assembly = 0; tiles the flags exclude (a tile row that straddles two bands or holds
+padding, a point outside the separable range) are still assembled and read.  Oracle comparisons ride along."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LL_RTOL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def gp():
+    import torch
+    torch.cuda.init()
+    import gpcc_amd
+    return gpcc_amd
+
+
+def _rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b)) / np.abs(np.asarray(b)))
+
+
+def _batch(Nl, y, M, seed, spread=12.0):
+    from gpcc_amd import synthetic
+    alpha, rho = synthetic.default_hyperparameters(y)
+    L = len(Nl)
+    rng = np.random.default_rng(seed)
+    delays = np.concatenate([np.zeros((M, 1)), rng.random((M, L - 1)) * spread], 1)
+    alphas = np.tile(alpha, (M, 1)) * (0.5 + rng.random((M, L)))
+    rhos = rho * (0.5 + rng.random(M))
+    return delays, alphas, rhos
+
+
+FUSED = (("right_looking_max", 0), ("shared_prefix", 0), ("fused_solve_min", 1), ("split_min", 0))
+
+
+@pytest.mark.parametrize("kname", ["OU", "matern32", "matern52", "rbf"])
+@pytest.mark.parametrize("Nl,mb", [([700, 600], True), ([700, 600], False), ([450, 400, 300], True), ([1100, 1000], True),
+                                   ([1024], True)])
+def test_folded_tiles_return_the_bits_of_assembled_tiles(gp, oracle, kname, Nl, mb):
+    """Same-band off-diagonal tiles with and without the B term, cross-band tiles, tile rows that straddle a band boundary, a ragged
+    last tile (padding), one band whose size is a multiple of the tile (no padding at all); groups of 64 + a remainder; an argument
+    error and an evaluation whose length scale puts its points OUTSIDE the separable range (flags 0: assembled and read)."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves(Nl, seed=33)
+    M = 70
+    delays, alphas, rhos = _batch(Nl, y, M, 5)
+    alphas[1, 0] = 0.0                       # argument error: info -1
+    span = max(tt.max() for tt in t) - min(tt.min() for tt in t)
+    rhos[2] = span / 5000.0                  # s (u - c) far beyond GPCC_SEP_MAX = 600 at the ends of the time axis
+    out = {}
+    with gp.Objective(t, y, s, getattr(gp, kname), marginalise_b=mb, slots_per_stream=64) as obj:
+        for k, v in FUSED:
+            obj.set_option(k, v)
+        assert obj.get_option("fold_assembly") == 1          # the default
+        for fold in (1, 0, 1):
+            obj.set_option("fold_assembly", fold)
+            ll, info = obj.loglik_batch(delays, alphas, rhos)
+            out.setdefault(fold, []).append((ll, info))
+    (a, ia), (a2, ia2) = out[1]
+    (b, ib), = out[0]
+    assert np.array_equal(a, a2, equal_nan=True) and np.array_equal(ia, ia2)          # repeatable
+    assert ia[1] == -1
+    assert np.array_equal(ia, ib)
+    assert np.array_equal(a, b, equal_nan=True)                                        # BITWISE
+    ok = ia == 0
+    assert ok.sum() >= M - 2
+    if sum(Nl) <= 1400:
+        ref, rinfo = oracle.loglik_batch(kname, t, y, s, delays, alphas, rhos, mb, nthreads=8)
+        assert np.array_equal(rinfo == 0, ok)
+        assert _rel(a[ok], ref[ok]) <= LL_RTOL
+
+
+def test_fold_is_taken_on_the_default_path_and_leaves_the_other_paths_alone(gp, oracle):
+    """Default options, a group of 130 (fused path: folded) and of 20 (three-kernel / right-looking: never folded) against the oracle;
+    the dense model matrix (gpcc_model_matrix: assembly only) is what it was."""
+    from gpcc_amd import synthetic
+    Nl = [400, 300]
+    t, y, s, _ = synthetic.simulate_lightcurves(Nl, seed=8)
+    for M in (130, 20):
+        delays, alphas, rhos = _batch(Nl, y, M, 3)
+        with gp.Objective(t, y, s, gp.matern32) as obj:
+            obj.set_option("shared_prefix", 0)
+            ll, info = obj.loglik_batch(delays, alphas, rhos)
+            obj.set_option("fold_assembly", 0)
+            ll0, info0 = obj.loglik_batch(delays, alphas, rhos)
+            K = obj.model_matrix(delays[0], alphas[0], rhos[0])
+        assert (info == 0).all() and (info0 == 0).all()
+        assert np.array_equal(ll, ll0)
+        ref, _ = oracle.loglik_batch("matern32", t, y, s, delays, alphas, rhos, True, nthreads=8)
+        assert _rel(ll, ref) <= LL_RTOL
+        Kref, _ = oracle.model_matrix("matern32", t, y, s, delays[0], alphas[0], rhos[0], True)
+        assert np.max(np.abs(K - Kref)) <= 1e-12 * np.max(np.abs(Kref))
