@@ -647,8 +647,8 @@ static int ensure_workspace(gpcc_handle_t h)
         if (e == hipSuccess) e = hipMalloc(&h->d_logdet, sizeof(double) * slots);
         if (e == hipSuccess) e = hipMalloc(&h->d_quad, sizeof(double) * GPCC_MAXRHS * GPCC_MAXRHS * slots);
         if (e == hipSuccess) e = hipMalloc(&h->d_info, sizeof(int) * slots);
-        if (e == hipSuccess) e = hipMalloc(&h->d_sep, sizeof(double) * 3 * h->Np * slots);
-        if (e == hipSuccess) e = hipMalloc(&h->d_seps, sizeof(double) * slots);
+        if (e == hipSuccess) e = hipMalloc(&h->d_sep, sizeof(double) * 4 * h->Np * slots);
+        if (e == hipSuccess) e = hipMalloc(&h->d_seps, sizeof(double) * 4 * slots);
         if (e == hipSuccess) e = hipMalloc(&h->d_sepflag, sizeof(int) * h->nt * slots);
         if (e == hipSuccess && h->precision == GPCC_PRECISION_FP32) {
             e = hipMalloc(&h->d_kdiag, sizeof(double) * h->Np * slots);
@@ -751,12 +751,15 @@ static int enqueue_group(gpcc_handle_t h, const GpccCtx &c_in, const GpccGroup &
     GpccCtx c = c_in;
     // fold: on the fused path every off-diagonal tile (I,k) is read exactly once, by the job that updates and solves it -- which can
     // evaluate the elements itself (gpcc_update_solve); only what the flags of gpcc_sep_points exclude is still assembled
-    c.fold = (factor && !ext && !single && h->fold_assembly && c.kernel_id != 1 && c.sep && c.nt > 1 && takes_fused_solve(h, c, g.cnt)) ? 1 : 0;
+    // (rbf is not separable: only its fp32 tiles evaluated in fp32 can be folded)
+    c.fold = (factor && !ext && h->fold_assembly && (c.kernel_id != 1 || (single && c.asm32)) && c.sep && c.nt > 1 &&
+              takes_fused_solve(h, c, g.cnt)) ? 1 : 0;
     if (c.fold) {
         ProfScope p(h, GPCC_PROF_ASSEMBLE, s);
         dim3 grid(c.nt, g.cnt);
         switch (c.kernel_id) {
         case 0: gpcc_sep_points<0><<<grid, GPCC_TILE, 0, s>>>(c, g); break;
+        case 1: gpcc_sep_points<1><<<grid, GPCC_TILE, 0, s>>>(c, g); break;
         case 2: gpcc_sep_points<2><<<grid, GPCC_TILE, 0, s>>>(c, g); break;
         default: gpcc_sep_points<3><<<grid, GPCC_TILE, 0, s>>>(c, g); break;
         }

@@ -76,11 +76,12 @@ struct GpccCtx {
     double *cond;    // slots x 2  : sum_i K_ii / d_i and max_i K_ii / d_i over the pivots d_i (fp32 mode only) -- the
                      //              a-posteriori conditioning measure behind the fp64 re-evaluation, DESIGN.md 4.7
     double tmid;     // midpoint of the observation times: centre of the separable-exponential form (gpcc_sep_point)
-    double *sep;     // slots x 3 x Np : shifted times u, separable factors A, B of every point (gpcc_sep_points; fold only)
-    double *seps;    // slots          : the kernel's scale of the distance, s (gpcc_kernel_scale)
-    int *sepflag;    // slots x nt     : tile row I lies inside ONE band b and all its points are in the separable range: b + 1; else 0
-    int fold;        // 1: the off-diagonal tiles whose two tile rows are flagged are NOT assembled -- gpcc_update_solve evaluates their
-                     //    elements into its accumulators (fused left-looking groups, fp64, the exponential kernels)
+    double *sep;     // slots x 4 x Np : shifted times u, separable factors A, B, amplitudes a of every point (gpcc_sep_points; fold only)
+    double *seps;    // slots x 4      : the kernel's scale of the distance s (gpcc_kernel_scale), its constants c1, c2 (gpcc_kernel_const)
+    int *sepflag;    // slots x nt     : low byte: b + 1 if tile row I lies inside ONE band b (no padding), else 0;
+                     //                  bit 8: all its points are in the range of the separable form (never set for rbf)
+    int fold;        // 1: the off-diagonal tiles inside one band pair are NOT assembled -- gpcc_update_solve evaluates their elements
+                     //    into its accumulators (fused left-looking groups; which tiles: gpcc_fold_mode)
     const double *t, *sig2, *resid;  // Np (padding: 0)
     const double *yv;                // Np: raw fluxes (only read by explicit 'Y' rows, see band codes)
     const int *band;                 // Np: >= 0 band of a real point; -1 identity padding;
@@ -376,8 +377,8 @@ __device__ __forceinline__ double gpcc_sep_eval(double ui, double uj, double Ai,
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool diag_tile(int I, int J) { return I == J; }
 
-// gpcc_sep_points (fold only): u, A, B of every point of `cnt` evaluations, the scale s and the per-tile-row flags of GpccCtx -- the
-// SAME values gpcc_assemble_tiles stages per tile (same functions, same arguments), computed once per evaluation.
+// gpcc_sep_points (fold only): u, A, B, a of every point of `cnt` evaluations, the kernel's constants and the per-tile-row flags of
+// GpccCtx -- the SAME values gpcc_assemble_tiles stages per tile (same functions, same arguments), computed once per evaluation.
 // grid (nt, cnt), block 128.
 template <int KID>
 __global__ __launch_bounds__(GPCC_TILE) void gpcc_sep_points(GpccCtx c, GpccGroup g)
@@ -392,30 +393,73 @@ __global__ __launch_bounds__(GPCC_TILE) void gpcc_sep_points(GpccCtx c, GpccGrou
     const double u_ = (b >= 0) ? c.t[gi] - delays[b] : 0.0;
     const double a_ = (b >= 0) ? alpha[b] : 0.0;
     double A_ = 0.0, B_ = 0.0;
-    const bool ok = gpcc_sep_point(u_, c.tmid, s, a_, A_, B_);
-    double *sp = c.sep + (long)slot * 3 * c.Np;
+    bool ok = false;
+    if (KID != 1) ok = gpcc_sep_point(u_, c.tmid, s, a_, A_, B_);
+    double *sp = c.sep + (long)slot * 4 * c.Np;
     sp[gi] = u_;
     sp[c.Np + gi] = A_;
     sp[2 * (long)c.Np + gi] = B_;
-    const int all = __syncthreads_and((ok && b >= 0 && b == b0) ? 1 : 0);
+    sp[3 * (long)c.Np + gi] = a_;
+    const int oneband = __syncthreads_and((b >= 0 && b == b0) ? 1 : 0);
+    const int inrange = __syncthreads_and(ok ? 1 : 0);
     if (r == 0) {
-        c.sepflag[(long)slot * c.nt + I] = all ? b0 + 1 : 0;
-        if (I == 0) c.seps[slot] = s;
+        c.sepflag[(long)slot * c.nt + I] = oneband ? ((b0 + 1) | (inrange ? 0x100 : 0)) : 0;
+        if (I == 0) {
+            c.seps[4 * (long)slot] = s;
+            c.seps[4 * (long)slot + 1] = kc.c1;
+            c.seps[4 * (long)slot + 2] = kc.c2;
+        }
     }
 }
 
+// How tile (I,J), I != J, of a folded group gets its elements (fI, fJ: the flags of its two tile rows): 0 = assembled by
+// gpcc_assemble_tiles and read back (a tile row that straddles bands or holds padding; points outside the separable range; rbf in
+// fp64), 1 = the separable form in fp64, rounded once for fp32 tiles, 2 = fp32 tiles evaluated in fp32 (GpccCtx::asm32; needs no B
+// term).  The SAME case distinction as in gpcc_assemble_tiles' select-free path, so that folded and assembled tiles agree bitwise.
+// bt_out: the B term of the tile.
+template <typename T>
+__device__ __forceinline__ int gpcc_fold_mode(const GpccCtx &c, int fI, int fJ, double &bt_out)
+{
+    const int bI = fI & 0xff, bJ = fJ & 0xff;
+    bt_out = 0.0;
+    if (bI == 0 || bJ == 0) return 0;
+    double bt = 0.0;
+    if (c.marginalise_b != 0 && !c.woodbury && bI == bJ) {
+#pragma unroll
+        for (int l = 0; l < GPCC_MAXL; ++l) bt = (bI - 1 == l) ? c.sigma_b[l] : bt;   // (no dynamic index into the kernel argument)
+    }
+    bt_out = bt;
+    if (sizeof(T) == 4 && c.asm32 && bt == 0.0) return 2;
+    return (c.kernel_id != 1 && (fI & fJ & 0x100) != 0) ? 1 : 0;
+}
+
 // the accumulators of tile (I,k) from the separable factors (gpcc_update_solve, fold): acc[cf][r'] = -K[row][16 cf + crow(q, r')],
-// the element exactly as gpcc_assemble_tiles' select-free path forms it (same expression, same operand order)
-template <int KID, typename P, typename ACC>
+// the element exactly as gpcc_assemble_tiles' select-free path forms it (same expression, same operand order, same rounding to T)
+template <int KID, typename T, typename ACC>
 __device__ __forceinline__ void gpcc_fold_init(ACC (&acc)[8], double ui, double Ai, double Bi, const double *cu, const double *cA,
                                                const double *cB, double s, double bt, int q)
 {
+    typedef GpccPrec<T> P;
 #pragma unroll
     for (int cf = 0; cf < 8; ++cf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = cf * 16 + P::crow(q, r);
-            acc[cf][r] = -(gpcc_sep_eval<KID>(ui, cu[j], Ai, Bi, cA[j], cB[j], s) + bt);
+            acc[cf][r] = -(T)(gpcc_sep_eval<KID>(ui, cu[j], Ai, Bi, cA[j], cB[j], s) + bt);
+        }
+}
+// ... and the fp32 evaluation of fp32 tiles (GpccCtx::asm32)
+template <int KID, typename T, typename ACC>
+__device__ __forceinline__ void gpcc_fold_init_f32(ACC (&acc)[8], double ui, float ai, const double *cu, float acol, float c1, float c2, int q)
+{
+    typedef GpccPrec<T> P;
+    const float amp = ai * acol;
+#pragma unroll
+    for (int cf = 0; cf < 8; ++cf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = cf * 16 + P::crow(q, r);
+            acc[cf][r] = -(T)(amp * gpcc_kernel_eval_f32<KID>((float)fabs(ui - cu[j]), c1, c2));
         }
 }
 
@@ -429,7 +473,10 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 4) void gpcc_assemble_til
     const int first_row = (c.share_p && m > 0) ? c.share_p : 0;   // followers of a shared prefix skip the leader's rows
     if (I < first_row) return;
     // fold: this tile is never read from memory -- gpcc_update_solve evaluates it into its accumulators (flags: gpcc_sep_points)
-    if (KID != 1 && c.fold && I != J && c.sepflag[(long)slot * c.nt + I] != 0 && c.sepflag[(long)slot * c.nt + J] != 0) return;
+    if (c.fold && I != J) {
+        double bt_;
+        if (gpcc_fold_mode<T>(c, c.sepflag[(long)slot * c.nt + I], c.sepflag[(long)slot * c.nt + J], bt_) != 0) return;
+    }
     const double *delays = g.delays + (long)(g.first + m) * c.L;
     const double *alpha = g.alpha + (long)(g.first + m) * c.L;
     const GpccKernelConst kc = gpcc_kernel_const<KID>(g.rho[g.first + m]);
@@ -885,25 +932,31 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
     // fold (round 4): a tile inside one band pair whose points are in the separable range was never assembled -- its elements are
     // evaluated here, from 2 x 128 points' factors (3 KiB, cached) instead of a 128 KiB tile written and read back; ~7 double-precision
     // operations per element = 0.5 % of the job's matrix work at the mean k, under the first chunk's LDS-DMA
-    int fI = 0, fk = 0;
-    if (SOLVE && sizeof(T) == 8 && c.fold) {
-        fI = __builtin_amdgcn_readfirstlane(c.sepflag[(long)slot * c.nt + I]);
-        fk = __builtin_amdgcn_readfirstlane(c.sepflag[(long)slot * c.nt + k]);
-    }
-    if (SOLVE && sizeof(T) == 8 && fI != 0 && fk != 0) {
-        const double *sp = c.sep + (long)slot * 3 * c.Np;
-        const double s = c.seps[slot];
-        double bt = 0.0;
-        if (c.marginalise_b != 0 && !c.woodbury && fI == fk) {
-#pragma unroll
-            for (int l = 0; l < GPCC_MAXL; ++l) bt = (fI - 1 == l) ? c.sigma_b[l] : bt;   // (no dynamic index into the kernel argument)
-        }
+    int fmode = 0;
+    double bt = 0.0;
+    if (SOLVE && c.fold)
+        fmode = gpcc_fold_mode<T>(c, __builtin_amdgcn_readfirstlane(c.sepflag[(long)slot * c.nt + I]),
+                                  __builtin_amdgcn_readfirstlane(c.sepflag[(long)slot * c.nt + k]), bt);
+    if (SOLVE && fmode != 0) {
+        const double *sp = c.sep + (long)slot * 4 * c.Np;
         const int ri = I * GPCC_TILE + wave * 16 + lr;
-        const double ui = sp[ri], Ai = sp[c.Np + ri], Bi = sp[2 * (long)c.Np + ri];
-        const double *cu = sp + k * GPCC_TILE, *cA = cu + c.Np, *cB = cA + c.Np;
-        if (c.kernel_id == 0) gpcc_fold_init<0, P>(acc, ui, Ai, Bi, cu, cA, cB, s, bt, q);
-        else if (c.kernel_id == 2) gpcc_fold_init<2, P>(acc, ui, Ai, Bi, cu, cA, cB, s, bt, q);
-        else gpcc_fold_init<3, P>(acc, ui, Ai, Bi, cu, cA, cB, s, bt, q);
+        const double ui = sp[ri];
+        const double *cu = sp + k * GPCC_TILE;
+        if (sizeof(T) == 4 && fmode == 2) {
+            const float ai = (float)sp[3 * (long)c.Np + ri], acol = (float)cu[3 * (long)c.Np];
+            const float c1 = (float)c.seps[4 * (long)slot + 1], c2 = (float)c.seps[4 * (long)slot + 2];
+            if (c.kernel_id == 0) gpcc_fold_init_f32<0, T>(acc, ui, ai, cu, acol, c1, c2, q);
+            else if (c.kernel_id == 1) gpcc_fold_init_f32<1, T>(acc, ui, ai, cu, acol, c1, c2, q);
+            else if (c.kernel_id == 2) gpcc_fold_init_f32<2, T>(acc, ui, ai, cu, acol, c1, c2, q);
+            else gpcc_fold_init_f32<3, T>(acc, ui, ai, cu, acol, c1, c2, q);
+        } else {
+            const double s = c.seps[4 * (long)slot];
+            const double Ai = sp[c.Np + ri], Bi = sp[2 * (long)c.Np + ri];
+            const double *cA = cu + c.Np, *cB = cA + c.Np;
+            if (c.kernel_id == 0) gpcc_fold_init<0, T>(acc, ui, Ai, Bi, cu, cA, cB, s, bt, q);
+            else if (c.kernel_id == 2) gpcc_fold_init<2, T>(acc, ui, Ai, Bi, cu, cA, cB, s, bt, q);
+            else gpcc_fold_init<3, T>(acc, ui, Ai, Bi, cu, cA, cB, s, bt, q);
+        }
     } else {
 #pragma unroll
         for (int cf = 0; cf < 8; ++cf)

@@ -95,3 +95,34 @@ def test_fold_is_taken_on_the_default_path_and_leaves_the_other_paths_alone(gp, 
         assert _rel(ll, ref) <= LL_RTOL
         Kref, _ = oracle.model_matrix("matern32", t, y, s, delays[0], alphas[0], rhos[0], True)
         assert np.max(np.abs(K - Kref)) <= 1e-12 * np.max(np.abs(Kref))
+
+
+@pytest.mark.parametrize("kname", ["OU", "matern32", "matern52", "rbf"])
+@pytest.mark.parametrize("Nl,mb,asm32", [([700, 600], True, 1), ([700, 600], False, 1), ([700, 600], True, 0), ([450, 400, 300], True, 1),
+                                         ([700, 600], False, 0)])
+def test_folded_fp32_tiles_return_the_bits_of_assembled_tiles(gp, oracle, kname, Nl, mb, asm32):
+    """fp32 handles: tiles evaluated in fp32 (fp32_assemble = 1: every kernel, rbf included) or in fp64 and rounded once
+    (fp32_assemble = 0: the separable form; rbf is then not folded at all) -- log-likelihoods, info and the guard's pivot-ratio
+    statistics bitwise those of fold_assembly = 0; then against the oracle at the fp32 tolerance."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves(Nl, seed=34)
+    M = 70
+    delays, alphas, rhos = _batch(Nl, y, M, 6)
+    alphas[1, 0] = 0.0
+    out = {}
+    with gp.Objective(t, y, s, getattr(gp, kname), marginalise_b=mb, precision="fp32", slots_per_stream=64) as obj:
+        for k, v in FUSED + (("fp32_assemble", asm32),):
+            obj.set_option(k, v)
+        for fold in (1, 0):
+            obj.set_option("fold_assembly", fold)
+            ll, info = obj.loglik_batch(delays, alphas, rhos)
+            out[fold] = (ll, info, obj.conditioning(M), obj.get_option("fp32_guard_count"))
+    a, ia, ca, na = out[1]
+    b, ib, cb, nb = out[0]
+    assert ia[1] == -1 and np.array_equal(ia, ib)
+    assert np.array_equal(a, b, equal_nan=True)                                        # BITWISE
+    assert np.array_equal(ca, cb, equal_nan=True)
+    ok = ia == 0
+    ref, rinfo = oracle.loglik_batch(kname, t, y, s, delays, alphas, rhos, mb, nthreads=8)
+    assert np.array_equal(rinfo == 0, ok)
+    assert _rel(a[ok], ref[ok]) <= 1e-3
