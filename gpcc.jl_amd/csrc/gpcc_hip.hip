@@ -125,6 +125,11 @@ struct gpcc_handle_s {
     int fused_solve_min = 112;   // ... from this group size on (below it the diagonal tile's serial K-loop on ONE CU per evaluation costs
                                  // more than the fused solve saves: measured crossover 96-128 evaluations at N = 1024 and N = 4096)
     int fused_solve = 1;     // option "fused_solve": left-looking groups run gpcc_syrk_diag + gpcc_update_solve (2 launches per step)
+    int look_ahead = 0;      // option "look_ahead": right-looking steps of the three-kernel path update column k + 1 first, then run its diagonal
+                             // step and panel solve beside the rest of the trailing update (which goes to a low-priority helper stream); bitwise
+                             // the same results.  OFF: the overlap works (profiles/r04/look_ahead_second_form_timeline.log) but the extra launch of
+                             // latency-bound single-tile jobs costs what the hidden chain saves: +1 % for 13-20 evaluations at N = 4096, -2 ... -5 %
+                             // for the split groups of 24-64 (profiles/r04/look_ahead_midsize_ab.log)
     int fold_assembly = 1;   // option "fold_assembly": fused left-looking fp64 groups of the exponential kernels do not assemble the off-diagonal
                              // tiles that lie inside one band pair; gpcc_update_solve evaluates them into its accumulators (GpccCtx::fold)
     int step_fused = 0;      // option "step_fused": ... as ONE launch per step (gpcc_step: the diagonal step of column k+1 inside the update
@@ -173,6 +178,8 @@ struct gpcc_handle_s {
     hipEvent_t ev_done[GPCC_MAX_STREAMS] = {};
     hipStream_t str2[GPCC_MAX_STREAMS] = {};      // second half of a split group (option "split_min")
     hipEvent_t ev_fork[GPCC_MAX_STREAMS] = {}, ev_join[GPCC_MAX_STREAMS] = {};
+    hipStream_t str_la[GPCC_MAX_STREAMS][2] = {};  // look-ahead helpers of str[] ([i][0]) and str2[] ([i][1]): the chain diagonal step -> panel solve
+    hipEvent_t ev_la[GPCC_MAX_STREAMS][2][2] = {}; // ... and their fork / join events (option "look_ahead")
     hipEvent_t ev_start = nullptr;
     hipStream_t main_stream = nullptr;
     // staging for the host-pointer API
@@ -429,6 +436,11 @@ static void free_workspace(gpcc_handle_t h)
         if (h->str2[s]) { hipStreamDestroy(h->str2[s]); h->str2[s] = nullptr; }
         if (h->ev_fork[s]) { hipEventDestroy(h->ev_fork[s]); h->ev_fork[s] = nullptr; }
         if (h->ev_join[s]) { hipEventDestroy(h->ev_join[s]); h->ev_join[s] = nullptr; }
+        for (int j = 0; j < 2; ++j) {
+            if (h->str_la[s][j]) { hipStreamDestroy(h->str_la[s][j]); h->str_la[s][j] = nullptr; }
+            for (int e = 0; e < 2; ++e)
+                if (h->ev_la[s][j][e]) { hipEventDestroy(h->ev_la[s][j][e]); h->ev_la[s][j][e] = nullptr; }
+        }
     }
     h->ws_ready = false;
 }
@@ -477,6 +489,8 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->update_t = (int)v;
     } else if (!strcmp(key, "fused_solve")) {
         h->fused_solve = v != 0;
+    } else if (!strcmp(key, "look_ahead")) {
+        h->look_ahead = v != 0;
     } else if (!strcmp(key, "fold_assembly")) {
         h->fold_assembly = v != 0;
     } else if (!strcmp(key, "step_fused")) {
@@ -552,6 +566,7 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "precision")) return h->precision;
     if (!strcmp(key, "fused_solve")) return h->fused_solve;
     if (!strcmp(key, "fused_solve_min")) return h->fused_solve_min;
+    if (!strcmp(key, "look_ahead")) return h->look_ahead;
     if (!strcmp(key, "fold_assembly")) return h->fold_assembly;
     if (!strcmp(key, "step_fused")) return h->step_fused;
     if (!strcmp(key, "diag_blocks")) return h->diag_blocks;
@@ -669,6 +684,15 @@ static int ensure_workspace(gpcc_handle_t h)
         HIPCHK(h, hipStreamCreateWithFlags(&h->str2[s], hipStreamNonBlocking));
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork[s], hipEventDisableTiming));
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[s], hipEventDisableTiming));
+        for (int j = 0; j < 2; ++j) {
+            {   // the helper runs the bulk of a trailing update; the chain on the main stream is the critical path and goes first
+                int prio_lo = 0, prio_hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+                HIPCHK(h, hipStreamCreateWithPriority(&h->str_la[s][j], hipStreamNonBlocking, prio_lo));
+            }
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_la[s][j][0], hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_la[s][j][1], hipEventDisableTiming));
+        }
     }
     { int rc_ = set_kernel_attributes(h); if (rc_) return rc_; }
     h->ws_streams = run_streams;
@@ -793,6 +817,18 @@ static int enqueue_group(gpcc_handle_t h, const GpccCtx &c_in, const GpccGroup &
     return 0;
 }
 
+// the look-ahead helper of a workspace stream (each of str[] / str2[] has its own stream and pair of events); false for any other stream
+static bool find_helper(gpcc_handle_t h, hipStream_t s, hipStream_t *sla, hipEvent_t *ev_a, hipEvent_t *ev_b)
+{
+    for (int i = 0; i < GPCC_MAX_STREAMS; ++i)
+        for (int j = 0; j < 2; ++j)
+            if (s && s == (j ? h->str2[i] : h->str[i]) && h->str_la[i][j]) {
+                *sla = h->str_la[i][j]; *ev_a = h->ev_la[i][j][0]; *ev_b = h->ev_la[i][j][1];
+                return true;
+            }
+    return false;
+}
+
 template <typename T>
 static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g_in, hipStream_t s, int concurrent)
 {
@@ -864,41 +900,68 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
         if (n > c.nt - 1) n = c.nt - 1;                                                      // (right-looking from step 1 on)
         if (n >= 2) ks = c.nt - n;
     }
+    // Look-ahead in the right-looking steps (round 4): the trailing update of step k is issued as "column k + 1 first" and "the rest";
+    // the diagonal step and the panel solve of column k + 1 -- a serial chain of two small launches, a fifth of a 16-evaluation group's
+    // time -- then run on a helper stream BESIDE the rest.  Unlike beside a full group's update, here the chain's few
+    // workgroups get CUs of their own.  Same jobs, same arithmetic: bitwise the results without it.
+    hipStream_t sla = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    const bool la = h->look_ahead && !h->prof && !p && c.nt_fact == c.nt && ks < c.nt - 1 && find_helper(h, s, &sla, &ev_a, &ev_b);
+    auto launch_diag = [&](int k, hipStream_t st) {
+        ProfScope pr(h, GPCC_PROF_DIAG, st);
+        if (h->diag_blocks && c.nrhs <= GPCC_DB_MAXRHS) gpcc_diag_factor2<T><<<(k < p) ? 1 : g.cnt, GPCC_DIAG_THREADS, GPCC_DB_LDS_BYTES, st>>>(c, g, k);
+        else gpcc_diag_factor<T><<<(k < p) ? 1 : g.cnt, GPCC_DIAG_THREADS, GPCC_DIAG_LDS_BYTES, st>>>(c, g, k);
+    };
+    auto launch_trsm = [&](int k, hipStream_t st) {
+        ProfScope pr(h, GPCC_PROF_TRSM, st);
+        const int grid = (k < p) ? cnt8 * (c.nt - p) + (p - k - 1) : cnt8 * (c.nt - k - 1);
+        if (!p && g.cnt * (c.nt - k - 1) <= h->trsm_rows_jobs)   // few jobs: quarter-tile jobs on four times as many CUs
+            gpcc_panel_trsm_rows<T><<<g.cnt * (c.nt - k - 1) * 4, 512, GPCC_TRSM_ROWS_LDS_BYTES, st>>>(c, g, k);
+        else if (grid > 0) gpcc_panel_trsm<T><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, st>>>(c, g, k);
+    };
     for (int k = 0; k < c.nt_fact; ++k) {
         const bool rstep = k >= ks;
         if (k > 0 && !rstep) {
             ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
             const int grid = (k < p) ? cnt8 * (c.nt - p) + (p - k) : cnt8 * (c.nt - k);
             if (h->update_t && !p && c.nt_fact == c.nt) gpcc_update_solve<T, false><<<grid, GPCC_GEMM_THREADS, GPCC_UPSOLVE_LDS_BYTES, s>>>(c, g, k);
-            else gpcc_panel_update<T, false><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, k, 0);
+            else gpcc_panel_update<T, false><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, k, 0, 0);
         }
         if (k > 0 && k == ks) {   // catch-up: all trailing tiles (I,J), I >= J >= ks, minus their sums over columns 0 .. ks-1
             ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
             const int n = c.nt - k;
-            gpcc_panel_update<T, true><<<cnt8 * (n * (n + 1) / 2), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k - 1, k, 0);
+            gpcc_panel_update<T, true><<<cnt8 * (n * (n + 1) / 2), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k - 1, k, 0, 0);
         }
-        {
-            ProfScope pr(h, GPCC_PROF_DIAG, s);
-            if (h->diag_blocks && c.nrhs <= GPCC_DB_MAXRHS) gpcc_diag_factor2<T><<<(k < p) ? 1 : g.cnt, GPCC_DIAG_THREADS, GPCC_DB_LDS_BYTES, s>>>(c, g, k);
-            else gpcc_diag_factor<T><<<(k < p) ? 1 : g.cnt, GPCC_DIAG_THREADS, GPCC_DIAG_LDS_BYTES, s>>>(c, g, k);
-        }
-        if (k < c.nt - 1) {
-            ProfScope pr(h, GPCC_PROF_TRSM, s);
-            const int grid = (k < p) ? cnt8 * (c.nt - p) + (p - k - 1) : cnt8 * (c.nt - k - 1);
-            if (!p && g.cnt * (c.nt - k - 1) <= h->trsm_rows_jobs)   // few jobs: quarter-tile jobs on four times as many CUs
-                gpcc_panel_trsm_rows<T><<<g.cnt * (c.nt - k - 1) * 4, 512, GPCC_TRSM_ROWS_LDS_BYTES, s>>>(c, g, k);
-            else if (grid > 0) gpcc_panel_trsm<T><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k);
+        if (!(la && k > ks)) {   // (with look-ahead, the chain of a right-looking step k > ks was issued by step k - 1)
+            launch_diag(k, s);
+            if (k < c.nt - 1) launch_trsm(k, s);
         }
         if (rstep && k < c.nt - 1) {
-            ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
             const int n = c.nt - k - 1;
-            gpcc_panel_update<T, true><<<cnt8 * (n * (n + 1) / 2), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, 1, k);
+            if (la) {
+                // the CHAIN stays on this stream (in order: the diagonal step's workgroups, which need a whole CU's LDS, are placed the
+                // moment column k + 1 is done -- on a helper stream they arrive a few microseconds after the rest has taken every CU and
+                // wait until it has drained: profiles/r04/look_ahead_first_form_timeline.log); the REST goes to the low-priority helper
+                gpcc_panel_update<T, true><<<cnt8 * n, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, 1, k, 1);
+                if (n >= 2) {
+                    (void)hipEventRecord(ev_a, s);
+                    (void)hipStreamWaitEvent(sla, ev_a, 0);
+                    gpcc_panel_update<T, true><<<cnt8 * ((n - 1) * n / 2), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, sla>>>(c, g, k, 1, k, 2);
+                    (void)hipEventRecord(ev_b, sla);
+                }
+                launch_diag(k + 1, s);
+                if (k + 1 < c.nt - 1) launch_trsm(k + 1, s);
+                if (n >= 2) (void)hipStreamWaitEvent(s, ev_b, 0);
+            } else {
+                ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
+                gpcc_panel_update<T, true><<<cnt8 * (n * (n + 1) / 2), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, 1, k, 0);
+            }
         }
     }
     // augmented systems: Schur complement of the rows beyond the factorised columns,
     // S = C - V^T V with V = L^-1 [cross block]  
     for (int k = c.nt_fact; k < c.nt; ++k)
-        gpcc_panel_update<T, false><<<cnt8 * (c.nt - k), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, c.nt_fact, 0);
+        gpcc_panel_update<T, false><<<cnt8 * (c.nt - k), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, c.nt_fact, 0, 0);
 }
 
 // left-looking blocked Cholesky + fused forward solve (+ Schur complement of non-factorised rows)
@@ -1009,6 +1072,8 @@ static int enqueue_batch(gpcc_handle_t h, int M, const double *d_delays, const d
         for (int s = 0; s < h->ws_streams; ++s) {
             if (h->str[s]) (void)hipStreamSynchronize(h->str[s]);
             if (h->str2[s]) (void)hipStreamSynchronize(h->str2[s]);
+            for (int j = 0; j < 2; ++j)
+                if (h->str_la[s][j]) (void)hipStreamSynchronize(h->str_la[s][j]);
         }
         (void)hipGetLastError();
         h->err = msg;

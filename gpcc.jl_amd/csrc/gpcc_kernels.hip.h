@@ -769,8 +769,11 @@ __device__ __forceinline__ void gpcc_dma_chunk(const T *gA, const T *gB, T *stag
 // kcol = first tile column of the K loop: 0 for the left-looking form, k for a right-looking step.  RIGHT with kcol = 0 and
 // ktiles = k + 1 is the CATCH-UP of a group that switches from left- to right-looking at step k + 1: every trailing tile
 // (I,J), I >= J > k, receives the whole sum over the finished columns 0..k at once.
+// part (RIGHT only; look-ahead, round 4): 0 = every trailing tile; 1 = the tiles of column k + 1 only -- what the diagonal step and the
+// panel solve of column k + 1 wait for; 2 = all the others (I >= J >= k + 2), which then run BESIDE that diagonal step on another
+// stream.  A tile's arithmetic is the same in every part.
 template <typename T, bool RIGHT>
-__global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup g, int k, int ktiles, int kcol)
+__global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup g, int k, int ktiles, int kcol, int part)
 {
     typedef GpccPrec<T> P;
     constexpr int CH = GPCC_CHUNK_BYTES / sizeof(T);
@@ -782,7 +785,7 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
 
     const int nrem = c.nt - k - 1;
     const bool shared = !RIGHT && c.share_p > k;   // step inside the shared prefix: B operand = the leader's row k
-    const int per = RIGHT ? nrem * (nrem + 1) / 2 : (shared ? c.nt - c.share_p : c.nt - k);
+    const int per = RIGHT ? (part == 1 ? nrem : part == 2 ? (nrem - 1) * nrem / 2 : nrem * (nrem + 1) / 2) : (shared ? c.nt - c.share_p : c.nt - k);
     const int nmain = 8 * ((g.cnt + 7) / 8) * per;
     const int x = blockIdx.x & 7, qq = blockIdx.x >> 3;
     int m = g.spread ? (int)blockIdx.x % g.cnt : (qq / per) * 8 + x;
@@ -797,13 +800,16 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
     } else if (shared) {
         I = c.share_p + jt;
         J = k;
+    } else if (RIGHT && part == 1) {
+        I = k + 1 + jt;
+        J = k + 1;
     } else if (RIGHT) {
-        const int j = jt;
+        const int j = jt, first = (part == 2) ? k + 2 : k + 1;
         int a = (int)((sqrtf(8.0f * j + 1.0f) - 1.0f) * 0.5f);
         while (a * (a + 1) / 2 > j) --a;
         while ((a + 1) * (a + 2) / 2 <= j) ++a;
-        I = k + 1 + a;
-        J = k + 1 + (j - a * (a + 1) / 2);
+        I = first + a;
+        J = first + (j - a * (a + 1) / 2);
     } else {
         I = k + jt;
         J = k;

@@ -101,6 +101,10 @@ int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms
  * most 4 right-hand sides, i.e. fp32 handles with more than 3 bands keep the round-2 kernels).  Both were built to let the
  * diagonal step run beside update workgroups and MEASURED not to pay (the fp64 matrix pipe bounds the step, and the pivot chain
  * runs 2-3x slower beside MFMA-saturating waves than alone on a CU: DESIGN.md 4.2e), hence off,
+ * "look_ahead" (round 4; 0 = default; 1: the right-looking steps of groups of 13-111 evaluations issue the trailing update as "column
+ * k + 1 first, then the rest" and run the diagonal step and panel solve of column k + 1 beside the rest, which goes to a low-priority
+ * helper stream -- LAPACK's look-ahead where the chain's few workgroups find CUs of their own; bitwise the results of 0.  Measured: the
+ * overlap works, the extra launch of single-tile jobs costs what it saves: +1 % for 13-20 evaluations, -2 ... -5 % for 24-64; off),
  * "fold_assembly" (round 4; 1 = default: fp64 groups on the fused_solve path with OU / Matern kernels do not write the off-diagonal
  * tiles of delayedCovariance that lie inside one band pair -- the update kernel evaluates those elements into its accumulators, the
  * same bits gpcc_model_matrix returns; 0 = every tile is assembled first, as in rounds 1-3),

@@ -147,3 +147,62 @@ def test_dense_factor_and_model_matrix_through_the_block_image(gp):
     Lref = np.linalg.cholesky(K)
     assert np.max(np.abs(Lf - Lref)) / np.max(np.abs(Lref)) <= 1e-9
     assert np.array_equal(np.triu(Lf, 1), np.zeros_like(K))
+
+
+@pytest.mark.parametrize("Nl,prec,mb", [([700, 600], "fp64", True), ([1100, 1000], "fp64", False), ([450, 400, 300], "fp32", True)])
+def test_right_looking_look_ahead_returns_the_same_bits(gp, oracle, Nl, prec, mb):
+    """Option look_ahead (three-kernel path, right-looking steps: column k+1 of the trailing update first, its diagonal step and panel
+    solve on a helper stream beside the rest): groups that are right-looking throughout, left-looking with a right-looking tail, split
+    into two halves on two streams (each with its own helper) -- bitwise the results of look_ahead = 0, an argument error included."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves(Nl, seed=22)
+    for M, opts in ((20, {"right_looking_max": 64, "fused_small_max": 0, "split_min": 0, "split_small": 0}),   # right-looking from step 0
+                    (7, {"right_looking_max": 64, "fused_small_max": 0, "split_min": 0, "split_small": 0}),    # ... with the spread job map
+                    (16, {"split_min": 0, "split_small": 0}),                                                 # left-looking + tail
+                    (40, {}),                                                                                  # default dispatch (split halves)
+                    (100, {"hybrid_occ": 4096, "hybrid_mall_mb": 4096})):                                      # a long tail
+        delays, alphas, rhos = _batch(Nl, y, M, M)
+        alphas[1, 0] = 0.0
+        res = {}
+        with gp.Objective(t, y, s, gp.matern32, marginalise_b=mb, precision=prec) as obj:
+            obj.set_option("shared_prefix", 0)
+            for k, v in opts.items():
+                obj.set_option(k, v)
+            assert obj.get_option("look_ahead") == 0     # an option, off by default (measured: DESIGN.md 4.2e)
+            for la in (1, 0, 1):
+                obj.set_option("look_ahead", la)
+                ll, info = obj.loglik_batch(delays, alphas, rhos)
+                res.setdefault(la, []).append((ll, info, obj.conditioning(M) if prec == "fp32" else None))
+        (a, ia, ca), (a2, ia2, _) = res[1]
+        (b, ib, cb), = res[0]
+        assert np.array_equal(a, a2, equal_nan=True) and np.array_equal(ia, ia2)
+        assert np.array_equal(ia, ib) and ia[1] == -1 and (np.delete(ia, 1) == 0).all()
+        assert np.array_equal(a, b, equal_nan=True)                                    # BITWISE
+        if ca is not None:
+            assert np.array_equal(ca, cb, equal_nan=True)
+        if M == 16:
+            ok = ia == 0
+            ref, rinfo = oracle.loglik_batch("matern32", t, y, s, delays, alphas, rhos, mb, nthreads=8)
+            assert _rel(a[ok], ref[ok]) <= (LL_RTOL if prec == "fp64" else FP32_RTOL)
+
+
+def test_a_failing_pivot_in_the_look_ahead_chain(gp):
+    """A non-positive pivot in a diagonal step that runs on the helper stream: the evaluation reports it (info > 0), its later jobs
+    return at once, the other evaluations of the group are unaffected; the same info with look_ahead = 0."""
+    from gpcc_amd import synthetic
+    Nl = [500, 400]
+    t, y, s, _ = synthetic.simulate_lightcurves(Nl, seed=4)
+    s0 = [np.full_like(x, 1e-9) for x in s]
+    M = 16
+    delays, alphas, rhos = _batch(Nl, y, M, 2)
+    rhos[3] = 1e6                                  # rbf, no noise to speak of, enormous length scale: numerically singular
+    out = []
+    with gp.Objective(t, y, s0, gp.rbf, marginalise_b=False) as obj:
+        for k, v in (("right_looking_max", 64), ("fused_small_max", 0), ("split_min", 0), ("split_small", 0), ("shared_prefix", 0)):
+            obj.set_option(k, v)
+        for la in (1, 0):
+            obj.set_option("look_ahead", la)
+            out.append(obj.loglik_batch(delays, alphas, rhos))
+    (a, ia), (b, ib) = out
+    assert ia[3] > 0 and np.array_equal(ia, ib)
+    assert np.array_equal(a, b, equal_nan=True)

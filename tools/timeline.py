@@ -20,6 +20,9 @@ if len(sys.argv) > 2 and sys.argv[1] == "--parse":
         first = idx[-nasm]
         rows = rows[first:]
         t0, t1 = rows[0][3], max(r[4] for r in rows)
+        if len(sys.argv) > 3 and sys.argv[3] == "dump":   # every launch of the batch: start, end (us from the first), grid
+            for n, g, w, s_, e_ in rows:
+                print("%9.1f %9.1f  %6d WG  %s" % ((s_ - t0) / 1e3, (e_ - t0) / 1e3, g // max(w, 1), n.split("(")[0].replace("void ", "")[:50]))
         per = {}
         for n, g, w, s, e in rows:
             k = n.split("(")[0].replace("void ", "")[:44]
