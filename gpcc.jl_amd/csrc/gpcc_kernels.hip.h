@@ -81,7 +81,8 @@ struct GpccCtx {
     int *sepflag;    // slots x nt     : low byte: b + 1 if tile row I lies inside ONE band b (no padding), else 0;
                      //                  bit 8: all its points are in the range of the separable form (never set for rbf)
     int fold;        // 1: the off-diagonal tiles inside one band pair are NOT assembled -- gpcc_update_solve evaluates their elements
-                     //    into its accumulators (fused left-looking groups; which tiles: gpcc_fold_mode)
+                     //    into its accumulators (fused left-looking groups; which tiles: gpcc_fold_mode);
+                     // 2: the three-kernel path: likewise for tile columns J >= 1, in the first gpcc_panel_update job that touches the tile
     const double *t, *sig2, *resid;  // Np (padding: 0)
     const double *yv;                // Np: raw fluxes (only read by explicit 'Y' rows, see band codes)
     const int *band;                 // Np: >= 0 band of a real point; -1 identity padding;
@@ -463,6 +464,41 @@ __device__ __forceinline__ void gpcc_fold_init_f32(ACC (&acc)[8], double ui, flo
         }
 }
 
+// ... and in gpcc_panel_update's accumulator layout (the three-kernel path, fold = 2): acc[fm][fn][r'] = -K[ro + 16 fm + crow(q, r')]
+// [co + 16 fn]; rp / cp point at the first row / this lane's first column of the per-point arrays (stride Np between u, A, B, a)
+template <int KID, int MODE, typename T, typename ACC>
+__device__ __forceinline__ void gpcc_fold_init_pu(ACC (&acc)[2][4], const double *rp, const double *cp, long Np, double s, double bt,
+                                                  float c1, float c2, int q)
+{
+    typedef GpccPrec<T> P;
+    double uj[4], Aj[4], Bj[4];
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) {
+        uj[fn] = cp[fn * 16];
+        if (MODE == 1) {
+            Aj[fn] = cp[Np + fn * 16];
+            Bj[fn] = cp[2 * Np + fn * 16];
+        }
+    }
+    const float acol = (MODE == 2) ? (float)cp[3 * Np] : 0.0f;
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = fm * 16 + P::crow(q, r);
+            const double ui = rp[i];
+            if (MODE == 1) {
+                const double Ai = rp[Np + i], Bi = rp[2 * Np + i];
+#pragma unroll
+                for (int fn = 0; fn < 4; ++fn) acc[fm][fn][r] = -(T)(gpcc_sep_eval<KID>(ui, uj[fn], Ai, Bi, Aj[fn], Bj[fn], s) + bt);
+            } else {
+                const float amp = (float)rp[3 * Np + i] * acol;
+#pragma unroll
+                for (int fn = 0; fn < 4; ++fn) acc[fm][fn][r] = -(T)(amp * gpcc_kernel_eval_f32<KID>((float)fabs(ui - uj[fn]), c1, c2));
+            }
+        }
+}
+
 template <int KID, bool EXT, typename T>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 4) void gpcc_assemble_tiles(GpccCtx c, GpccGroup g)
 {
@@ -473,7 +509,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 4) void gpcc_assemble_til
     const int first_row = (c.share_p && m > 0) ? c.share_p : 0;   // followers of a shared prefix skip the leader's rows
     if (I < first_row) return;
     // fold: this tile is never read from memory -- gpcc_update_solve evaluates it into its accumulators (flags: gpcc_sep_points)
-    if (c.fold && I != J) {
+    if (c.fold && I != J && (c.fold == 1 || J >= 1)) {   // (fold = 2, the three-kernel path: column 0 goes straight to the panel solve)
         double bt_;
         if (gpcc_fold_mode<T>(c, c.sepflag[(long)slot * c.nt + I], c.sepflag[(long)slot * c.nt + J], bt_) != 0) return;
     }
@@ -828,13 +864,38 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
     gpcc_dma_chunk_at<T>(gA, gB, smem_addr, wave, lane);
 
     typename P::acc_t acc[2][4];
+    // fold = 2 (round 4): the FIRST job that touches an off-diagonal tile (I,J), J >= 1 -- the left-looking update of column J, or the
+    // right-looking step / catch-up whose K loop starts at column 0 -- evaluates its elements instead of reading an assembled tile
+    int fmode = 0;
+    double bt = 0.0;
+    if (c.fold == 2 && I != J && (!RIGHT || kcol == 0))
+        fmode = gpcc_fold_mode<T>(c, __builtin_amdgcn_readfirstlane(c.sepflag[(long)slot * c.nt + I]),
+                                  __builtin_amdgcn_readfirstlane(c.sepflag[(long)slot * c.nt + J]), bt);
+    if (fmode != 0) {
+        const double *sp = c.sep + (long)slot * 4 * c.Np;
+        const double *rp = sp + I * GPCC_TILE + wr * 32, *cp = sp + J * GPCC_TILE + wc * 64 + lr;
+        const double s = c.seps[4 * (long)slot];
+        const float c1 = (float)c.seps[4 * (long)slot + 1], c2 = (float)c.seps[4 * (long)slot + 2];
+        const long Np = c.Np;
+        if (sizeof(T) == 4 && fmode == 2) {
+            if (c.kernel_id == 0) gpcc_fold_init_pu<0, 2, T>(acc, rp, cp, Np, s, bt, c1, c2, q);
+            else if (c.kernel_id == 1) gpcc_fold_init_pu<1, 2, T>(acc, rp, cp, Np, s, bt, c1, c2, q);
+            else if (c.kernel_id == 2) gpcc_fold_init_pu<2, 2, T>(acc, rp, cp, Np, s, bt, c1, c2, q);
+            else gpcc_fold_init_pu<3, 2, T>(acc, rp, cp, Np, s, bt, c1, c2, q);
+        } else {
+            if (c.kernel_id == 0) gpcc_fold_init_pu<0, 1, T>(acc, rp, cp, Np, s, bt, c1, c2, q);
+            else if (c.kernel_id == 2) gpcc_fold_init_pu<2, 1, T>(acc, rp, cp, Np, s, bt, c1, c2, q);
+            else gpcc_fold_init_pu<3, 1, T>(acc, rp, cp, Np, s, bt, c1, c2, q);
+        }
+    } else {
 #pragma unroll
-    for (int fm = 0; fm < 2; ++fm)
+        for (int fm = 0; fm < 2; ++fm)
 #pragma unroll
-        for (int fn = 0; fn < 4; ++fn)
+            for (int fn = 0; fn < 4; ++fn)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc[fm][fn][r] = -Tt[gpcc_elem_off<T>(wr * 32 + fm * 16 + P::crow(q, r), wc * 64 + fn * 16 + lr)];
+                for (int r = 0; r < 4; ++r)
+                    acc[fm][fn][r] = -Tt[gpcc_elem_off<T>(wr * 32 + fm * 16 + P::crow(q, r), wc * 64 + fn * 16 + lr)];
+    }
 
     // per-lane LDS addresses: one base per 16-byte slot, fragments/stages are immediates from it.
     // lane (lr, q) holds k = KSTEPS*q .. KSTEPS*q + KSTEPS-1 of its row: the MFMA sums over q, the steps over s

@@ -36,6 +36,48 @@ def _batch(Nl, y, M, seed, spread=12.0):
 
 
 FUSED = (("right_looking_max", 0), ("shared_prefix", 0), ("fused_solve_min", 1), ("split_min", 0))
+# the three-kernel path (fold = 2: the first gpcc_panel_update job that touches a tile evaluates it): left-looking with a right-looking
+# tail, right-looking from step 0 (also with the look-ahead's two-part update), the default dispatch of 40 (two halves on two streams)
+THREE = {"tail": (16, (("shared_prefix", 0), ("split_min", 0), ("split_small", 0))),
+         "left": (16, (("shared_prefix", 0), ("split_min", 0), ("split_small", 0), ("hybrid_tail", 0))),
+         "right": (20, (("shared_prefix", 0), ("right_looking_max", 64), ("fused_small_max", 0), ("split_min", 0), ("split_small", 0))),
+         "right+la": (20, (("shared_prefix", 0), ("right_looking_max", 64), ("fused_small_max", 0), ("split_min", 0), ("split_small", 0),
+                           ("look_ahead", 1))),
+         "spread": (5, (("shared_prefix", 0), ("fused_small_max", 0), ("split_min", 0), ("split_small", 0))),
+         "default40": (40, (("shared_prefix", 0),))}
+
+
+@pytest.mark.parametrize("path", sorted(THREE))
+@pytest.mark.parametrize("kname,prec,asm32", [("matern32", "fp64", 1), ("OU", "fp64", 1), ("matern52", "fp32", 1), ("rbf", "fp32", 1),
+                                               ("matern32", "fp32", 0)])
+def test_three_kernel_path_folded_tiles_return_the_bits_of_assembled_tiles(gp, oracle, path, kname, prec, asm32):
+    from gpcc_amd import synthetic
+    Nl = [700, 600]
+    t, y, s, _ = synthetic.simulate_lightcurves(Nl, seed=35)
+    M, opts = THREE[path]
+    delays, alphas, rhos = _batch(Nl, y, M, 7)
+    alphas[1, 0] = 0.0
+    span = max(tt.max() for tt in t) - min(tt.min() for tt in t)
+    rhos[2] = span / 5000.0
+    out = {}
+    with gp.Objective(t, y, s, getattr(gp, kname), precision=prec) as obj:
+        for k, v in opts:
+            obj.set_option(k, v)
+        if prec == "fp32":
+            obj.set_option("fp32_assemble", asm32)
+        for fold in (1, 0):
+            obj.set_option("fold_assembly", fold)
+            ll, info = obj.loglik_batch(delays, alphas, rhos)
+            out[fold] = (ll, info, obj.conditioning(M) if prec == "fp32" else None)
+    a, ia, ca = out[1]
+    b, ib, cb = out[0]
+    assert ia[1] == -1 and np.array_equal(ia, ib)
+    assert np.array_equal(a, b, equal_nan=True)                                        # BITWISE
+    if ca is not None:
+        assert np.array_equal(ca, cb, equal_nan=True)
+    ok = ia == 0
+    ref, rinfo = oracle.loglik_batch(kname, t, y, s, delays, alphas, rhos, True, nthreads=8)
+    assert _rel(a[ok], ref[ok]) <= (LL_RTOL if prec == "fp64" else 1e-3)
 
 
 @pytest.mark.parametrize("kname", ["OU", "matern32", "matern52", "rbf"])
