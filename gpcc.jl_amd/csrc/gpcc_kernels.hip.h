@@ -544,9 +544,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 4) void gpcc_assemble_til
         const double a_ = (b >= 0) ? alpha[b] : 0.0;
         su[side][r] = u_;
         sa[side][r] = a_;
-        if (KID != 1 && I != J) {   // (off-diagonal tiles only: the select-free path below is the one that uses them)
+        if (KID != 1) {   // (padding / explicit rows: amplitude 0, placed at the centre so that they never leave the range)
             double A_, B_;
-            sep_ok = gpcc_sep_point(u_, c.tmid, gpcc_kernel_scale<KID>(kc), a_, A_, B_);
+            sep_ok = gpcc_sep_point((b >= 0) ? u_ : c.tmid, c.tmid, gpcc_kernel_scale<KID>(kc), a_, A_, B_);
             sA[side][r] = A_;
             sB[side][r] = B_;
         }
@@ -657,6 +657,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 4) void gpcc_assemble_til
         const int r = (tid >> 3) + 32 * j;  // row data stays in registers across the chunks
         const int br = sb[0][r];
         const double ur = su[0][r], ar = sa[0][r], sg = ssig[r];
+        const double Ar = (KID != 1) ? sA[0][r] : 0.0, Br = (KID != 1) ? sB[0][r] : 0.0;
+        const double kscale_g = gpcc_kernel_scale<KID>(kc);
         const double bterm = (mb && br >= 0) ? ssb[br] : 0.0;
         const int cs = (sp ^ gpcc_sw(r)) * P::EP;  // logical column (inside a chunk) stored in slot sp
 #pragma unroll
@@ -667,8 +669,11 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 4) void gpcc_assemble_til
             for (int h = 0; h < P::EP; ++h) {
                 const int cc = col + h;
                 const int bc = sb[1][cc];
-                const double kv = gpcc_kernel_eval<KID>(ur, su[1][cc], kc);  // x - delays[i] vs y - delays[j]
-                double val = (ar * sa[1][cc]) * kv;                          // scale[i]*scale[j]*kernel
+                // scale[i]*scale[j]*kernel(x - delays[i], y - delays[j]): the separable form here too (round 4: with three bands a
+                // quarter of the tiles straddle a band boundary, and the 28-operation element made them cost as much as all the others)
+                double val;
+                if (KID != 1 && sep) val = gpcc_sep_eval<KID>(ur, su[1][cc], Ar, Br, sA[1][cc], sB[1][cc], kscale_g);
+                else val = (ar * sa[1][cc]) * gpcc_kernel_eval<KID>(ur, su[1][cc], kc);
                 if (diag && r == cc) val = val + sg;                         // + Sobs
                 if (br == bc) val = val + bterm;                             // + B = Q Sigma_b Q'
                 if (br < 0 || bc < 0) val = (diag && r == cc) ? 1.0 : 0.0;   // identity padding
@@ -2736,9 +2741,9 @@ __global__ __launch_bounds__(256) void gpcc_refine_partials(GpccCtx c, GpccGroup
         const double u_ = (b >= 0) ? c.t[gi] - delays[b] : 0.0, a_ = (b >= 0) ? alpha[b] : 0.0;
         su[side][r] = u_;
         sa[side][r] = a_;
-        if (KID != 1 && I != J) {
+        if (KID != 1) {   // (padding: amplitude 0, placed at the centre)
             double A_, B_;
-            sep_ok = gpcc_sep_point(u_, c.tmid, gpcc_kernel_scale<KID>(kc), a_, A_, B_);
+            sep_ok = gpcc_sep_point((b >= 0) ? u_ : c.tmid, c.tmid, gpcc_kernel_scale<KID>(kc), a_, A_, B_);
             sA[side][r] = A_;
             sB[side][r] = B_;
         }
@@ -2762,15 +2767,59 @@ __global__ __launch_bounds__(256) void gpcc_refine_partials(GpccCtx c, GpccGroup
         // 18 instead of 22 double-rate operations per element; the element agrees with the assembly's to an ulp or two
         const double kscale = (KID == 0) ? kc.c1 : (KID == 1) ? 0.5 * kc.c1 : (KID == 2) ? 1.7320508075688772 * kc.c1 : 2.23606797749979 * kc.c1;
         if (KID != 1 && sep) {   // the separable form (as the assembly): no exponential per element, the amplitudes inside the factors
-            const double Ar = sA[0][i], Br = sB[0][i];
-#pragma unroll 4
-            for (int jj = 0; jj < 64; ++jj) {
-                const int j = half * 64 + jj;
-                const double kv = gpcc_sep_eval<KID>(ur, su[1][j], Ar, Br, sA[1][j], sB[1][j], kscale);
+            // Register-blocked (round 4): a thread owns FOUR rows (i0, i0 + 32, ...) and 16 columns, so the 3 + nrhs LDS reads of a column
+            // serve four elements -- with one row per thread the loop was bound by the issue of its LDS reads (6 per element and wave
+            // at nrhs = 3, 4 cycles each on the CU's one LDS, against 40 cycles of arithmetic on the wave's own SIMD)
+            const int i0 = tid & 31, cg = tid >> 5;
+            double ur4[4], Ar4[4], Br4[4], s4[4][NA];
 #pragma unroll
-                for (int a = 0; a < NA; ++a)
-                    if (NR || a < nrhs) s[a] = fma(kv, sx[1][a][j], s[a]);
+            for (int r = 0; r < 4; ++r) {
+                ur4[r] = su[0][i0 + 32 * r];
+                Ar4[r] = sA[0][i0 + 32 * r];
+                Br4[r] = sB[0][i0 + 32 * r];
+#pragma unroll
+                for (int a = 0; a < NA; ++a) s4[r][a] = 0.0;
             }
+#pragma unroll 2
+            for (int jj = 0; jj < 16; ++jj) {
+                const int j = cg * 16 + jj;
+                const double uj = su[1][j], Aj = sA[1][j], Bj = sB[1][j];
+                double xj[NA];
+#pragma unroll
+                for (int a = 0; a < NA; ++a) xj[a] = (NR || a < nrhs) ? sx[1][a][j] : 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double kv = gpcc_sep_eval<KID>(ur4[r], uj, Ar4[r], Br4[r], Aj, Bj, kscale);
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) s4[r][a] = fma(kv, xj[a], s4[r][a]);
+                }
+            }
+            // this thread's contribution to every (a,b) over its four rows (off-diagonal tile: both (I,J) and (J,I)), then the fixed tree
+            const int lane_ = tid & 63, wave_ = tid >> 6;
+            for (int a = 0; a < nrhs; ++a)
+                for (int b = a; b < nrhs; ++b) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        double sa_ = 0.0, sb_ = 0.0;
+#pragma unroll
+                        for (int e = 0; e < NA; ++e) {   // (s4 stays in registers: no dynamic index)
+                            sa_ = (e == a) ? s4[r][e] : sa_;
+                            sb_ = (e == b) ? s4[r][e] : sb_;
+                        }
+                        v = fma(sx[0][a][i0 + 32 * r], sb_, v);
+                        v = fma(sx[0][b][i0 + 32 * r], sa_, v);
+                    }
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+                    if (lane_ == 0) sred[wave_][a * nrhs + b] = sred[wave_][b * nrhs + a] = v;
+                }
+            __syncthreads();
+            if (tid < nrhs * nrhs) {
+                const long tidx = (long)I * (I + 1) / 2 + J, ntri = (long)c.nt * (c.nt + 1) / 2;
+                c.gpart[((long)slot * ntri + tidx) * (GPCC_MAXRHS * GPCC_MAXRHS) + tid] = ((sred[0][tid] + sred[1][tid]) + sred[2][tid]) + sred[3][tid];
+            }
+            return;
         } else {
 #pragma unroll 4
         for (int jj = 0; jj < 64; ++jj) {
@@ -2793,11 +2842,15 @@ __global__ __launch_bounds__(256) void gpcc_refine_partials(GpccCtx c, GpccGroup
         for (int a = 0; a < NA; ++a) s[a] *= amp;
         }
     } else {
+        const double Ar_g = (KID != 1) ? sA[0][i] : 0.0, Br_g = (KID != 1) ? sB[0][i] : 0.0;
+        const double kscale_g = gpcc_kernel_scale<KID>(kc);
 #pragma unroll 4
         for (int jj = 0; jj < 64; ++jj) {
             const int j = half * 64 + jj;
             const int bc = sb[1][j];
-            double val = (ar * sa[1][j]) * gpcc_kernel_eval<KID>(ur, su[1][j], kc, sexp);
+            double val;
+            if (KID != 1 && sep) val = gpcc_sep_eval<KID>(ur, su[1][j], Ar_g, Br_g, sA[1][j], sB[1][j], kscale_g);   // (as the assembly)
+            else val = (ar * sa[1][j]) * gpcc_kernel_eval<KID>(ur, su[1][j], kc, sexp);
             if (diag && i == j) val = val + sg;
             if (br < 0 || bc < 0) val = 0.0;   // padding / explicit rows: X is zero there
 #pragma unroll
