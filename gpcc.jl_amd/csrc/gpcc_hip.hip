@@ -156,6 +156,7 @@ struct gpcc_handle_s {
                              // the matrix in registers; always fp64) instead of the tile kernels
     std::atomic<long> small_count{0};   // evaluations that took that path so far ("small_n_count")
     int small_wide_max = 512;           // option "small_wide_max": batches of at most this many evaluations (two workgroups per CU) run four waves per evaluation
+    bool mixed_rows = false; // some tile row straddles two bands or holds padding (GpccCtx::fold_mixed)
     int share_tiles = 0;     // tile rows wholly inside band 1
     bool share_now = false;  // decision for the batch being enqueued
     // workspace
@@ -395,6 +396,8 @@ extern "C" int gpcc_create(gpcc_handle_t *out, int L, const int *Nl, const doubl
     h->sig2_host.assign(hs.begin(), hs.begin() + N);
     h->sigma_host.assign(sigma, sigma + N);
     h->band_host.assign(hb.begin(), hb.begin() + N);
+    h->mixed_rows = (N % GPCC_TILE) != 0;   // (padding in the last tile row)
+    for (long i = 0; i < N && !h->mixed_rows; ++i) h->mixed_rows = hb[i] != hb[i - i % GPCC_TILE];
 #define CR(call)                                                                                             \
     do {                                                                                                     \
         hipError_t e_ = (call);                                                                              \
@@ -627,6 +630,12 @@ static int set_kernel_attributes(gpcc_handle_t h)
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_update_solve<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_update_solve<double, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_update_solve<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_update_solve<double, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_update_solve<float, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<double, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<double, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<float, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<float, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_step<double>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_step<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_diag_factor2<double>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_DB_LDS_BYTES));
@@ -718,7 +727,7 @@ static GpccCtx make_ctx(gpcc_handle_t h)
     c.linv_keep = (h->precision == GPCC_PRECISION_FP32) ? 1 : 2;
     c.t = h->d_t; c.sig2 = h->d_sig2; c.resid = h->d_resid; c.band = h->d_band; c.yv = h->d_yv;
     c.tmid = h->tmid;
-    c.sep = h->d_sep; c.seps = h->d_seps; c.sepflag = h->d_sepflag; c.fold = 0;
+    c.sep = h->d_sep; c.seps = h->d_seps; c.sepflag = h->d_sepflag; c.fold = 0; c.fold_mixed = 0;
     for (int l = 0; l < GPCC_MAXL; ++l) c.sigma_b[l] = (l < h->L) ? h->sigma_b[l] : 0.0;
     c.slot_stride = h->slot_stride;
     c.L = h->L; c.N = h->N; c.Np = h->Np; c.nt = h->nt; c.kernel_id = h->kernel_id; c.marginalise_b = h->mb;
@@ -782,6 +791,9 @@ static int enqueue_group(gpcc_handle_t h, const GpccCtx &c_in, const GpccGroup &
         const bool right = g.cnt <= h->right_looking_max;
         if (takes_fused_solve(h, c, g.cnt)) c.fold = 1;
         else if (!(right && g.cnt <= h->fused_small_max) && !h->update_t) c.fold = 2;   // (not the gpcc_small_step path of a few evaluations)
+        // tile rows that straddle two bands or hold padding: the MIXED instantiations (a handle without such rows keeps the leaner ones;
+        // gpcc_step has no MIXED form)
+        c.fold_mixed = (c.fold && h->mixed_rows && !(c.fold == 1 && h->step_fused)) ? 1 : 0;
     }
     if (c.fold) {
         ProfScope p(h, GPCC_PROF_ASSEMBLE, s);
@@ -882,7 +894,8 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
             }
             if (k < c.nt - 1) {
                 ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
-                gpcc_update_solve<T, true><<<cnt8 * (c.nt - k - 1), GPCC_GEMM_THREADS, GPCC_UPSOLVE_LDS_BYTES, s>>>(c, g, k);
+                if (c.fold_mixed) gpcc_update_solve<T, true, true><<<cnt8 * (c.nt - k - 1), GPCC_GEMM_THREADS, GPCC_UPSOLVE_LDS_BYTES, s>>>(c, g, k);
+                else gpcc_update_solve<T, true><<<cnt8 * (c.nt - k - 1), GPCC_GEMM_THREADS, GPCC_UPSOLVE_LDS_BYTES, s>>>(c, g, k);
             }
         }
         return;
@@ -924,18 +937,23 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
             gpcc_panel_trsm_rows<T><<<g.cnt * (c.nt - k - 1) * 4, 512, GPCC_TRSM_ROWS_LDS_BYTES, st>>>(c, g, k);
         else if (grid > 0) gpcc_panel_trsm<T><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, st>>>(c, g, k);
     };
+    auto launch_right = [&](int grid, hipStream_t st, int k, int ktiles, int kcol, int part) {   // (only a launch whose K loop starts at column 0 folds)
+        if (c.fold_mixed && kcol == 0) gpcc_panel_update<T, true, true><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, st>>>(c, g, k, ktiles, kcol, part);
+        else gpcc_panel_update<T, true><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, st>>>(c, g, k, ktiles, kcol, part);
+    };
     for (int k = 0; k < c.nt_fact; ++k) {
         const bool rstep = k >= ks;
         if (k > 0 && !rstep) {
             ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
             const int grid = (k < p) ? cnt8 * (c.nt - p) + (p - k) : cnt8 * (c.nt - k);
             if (h->update_t && !p && c.nt_fact == c.nt) gpcc_update_solve<T, false><<<grid, GPCC_GEMM_THREADS, GPCC_UPSOLVE_LDS_BYTES, s>>>(c, g, k);
+            else if (c.fold_mixed) gpcc_panel_update<T, false, true><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, k, 0, 0);
             else gpcc_panel_update<T, false><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, k, 0, 0);
         }
         if (k > 0 && k == ks) {   // catch-up: all trailing tiles (I,J), I >= J >= ks, minus their sums over columns 0 .. ks-1
             ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
             const int n = c.nt - k;
-            gpcc_panel_update<T, true><<<cnt8 * (n * (n + 1) / 2), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k - 1, k, 0, 0);
+            launch_right(cnt8 * (n * (n + 1) / 2), s, k - 1, k, 0, 0);
         }
         if (!(la && k > ks)) {   // (with look-ahead, the chain of a right-looking step k > ks was issued by step k - 1)
             launch_diag(k, s);
@@ -947,11 +965,11 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
                 // the CHAIN stays on this stream (in order: the diagonal step's workgroups, which need a whole CU's LDS, are placed the
                 // moment column k + 1 is done -- on a helper stream they arrive a few microseconds after the rest has taken every CU and
                 // wait until it has drained: profiles/r04/look_ahead_first_form_timeline.log); the REST goes to the low-priority helper
-                gpcc_panel_update<T, true><<<cnt8 * n, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, 1, k, 1);
+                launch_right(cnt8 * n, s, k, 1, k, 1);
                 if (n >= 2) {
                     (void)hipEventRecord(ev_a, s);
                     (void)hipStreamWaitEvent(sla, ev_a, 0);
-                    gpcc_panel_update<T, true><<<cnt8 * ((n - 1) * n / 2), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, sla>>>(c, g, k, 1, k, 2);
+                    launch_right(cnt8 * ((n - 1) * n / 2), sla, k, 1, k, 2);
                     (void)hipEventRecord(ev_b, sla);
                 }
                 launch_diag(k + 1, s);
@@ -959,7 +977,7 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
                 if (n >= 2) (void)hipStreamWaitEvent(s, ev_b, 0);
             } else {
                 ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
-                gpcc_panel_update<T, true><<<cnt8 * (n * (n + 1) / 2), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, 1, k, 0);
+                launch_right(cnt8 * (n * (n + 1) / 2), s, k, 1, k, 0);
             }
         }
     }

@@ -83,6 +83,8 @@ struct GpccCtx {
     int fold;        // 1: the off-diagonal tiles inside one band pair are NOT assembled -- gpcc_update_solve evaluates their elements
                      //    into its accumulators (fused left-looking groups; which tiles: gpcc_fold_mode);
                      // 2: the three-kernel path: likewise for tile columns J >= 1, in the first gpcc_panel_update job that touches the tile
+    int fold_mixed;  // 1: ... also the tiles of a tile row that straddles two bands or holds padding (gpcc_fold_mode 3; the MIXED
+                     //    instantiations of the two kernels: the host launches those when it sets this)
     const double *t, *sig2, *resid;  // Np (padding: 0)
     const double *yv;                // Np: raw fluxes (only read by explicit 'Y' rows, see band codes)
     const int *band;                 // Np: >= 0 band of a real point; -1 identity padding;
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(GPCC_TILE) void gpcc_sep_points(GpccCtx c, GpccGrou
     const double a_ = (b >= 0) ? alpha[b] : 0.0;
     double A_ = 0.0, B_ = 0.0;
     bool ok = false;
-    if (KID != 1) ok = gpcc_sep_point(u_, c.tmid, s, a_, A_, B_);
+    if (KID != 1) ok = gpcc_sep_point((b >= 0) ? u_ : c.tmid, c.tmid, s, a_, A_, B_);   // (padding: amplitude 0, at the centre -- as the assembly)
     double *sp = c.sep + (long)slot * 4 * c.Np;
     sp[gi] = u_;
     sp[c.Np + gi] = A_;
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(GPCC_TILE) void gpcc_sep_points(GpccCtx c, GpccGrou
     const int oneband = __syncthreads_and((b >= 0 && b == b0) ? 1 : 0);
     const int inrange = __syncthreads_and(ok ? 1 : 0);
     if (r == 0) {
-        c.sepflag[(long)slot * c.nt + I] = oneband ? ((b0 + 1) | (inrange ? 0x100 : 0)) : 0;
+        c.sepflag[(long)slot * c.nt + I] = (oneband ? b0 + 1 : 0) | (inrange ? 0x100 : 0);
         if (I == 0) {
             c.seps[4 * (long)slot] = s;
             c.seps[4 * (long)slot + 1] = kc.c1;
@@ -414,16 +416,17 @@ __global__ __launch_bounds__(GPCC_TILE) void gpcc_sep_points(GpccCtx c, GpccGrou
 }
 
 // How tile (I,J), I != J, of a folded group gets its elements (fI, fJ: the flags of its two tile rows): 0 = assembled by
-// gpcc_assemble_tiles and read back (a tile row that straddles bands or holds padding; points outside the separable range; rbf in
+// gpcc_assemble_tiles and read back (points outside the separable range; rbf in fp64 or in a tile row that straddles bands; rbf in
 // fp64), 1 = the separable form in fp64, rounded once for fp32 tiles, 2 = fp32 tiles evaluated in fp32 (GpccCtx::asm32; needs no B
-// term).  The SAME case distinction as in gpcc_assemble_tiles' select-free path, so that folded and assembled tiles agree bitwise.
-// bt_out: the B term of the tile.
+// term), 3 = a tile row that straddles two bands or holds padding: the separable form with the B term and the padding decided per
+// element (gpcc_assemble_tiles' general path).  The SAME case distinction as in gpcc_assemble_tiles, so that folded and assembled
+// tiles agree bitwise.  bt_out: the B term of a tile inside one band pair.
 template <typename T>
 __device__ __forceinline__ int gpcc_fold_mode(const GpccCtx &c, int fI, int fJ, double &bt_out)
 {
     const int bI = fI & 0xff, bJ = fJ & 0xff;
     bt_out = 0.0;
-    if (bI == 0 || bJ == 0) return 0;
+    if (bI == 0 || bJ == 0) return (c.fold_mixed && c.kernel_id != 1 && (fI & fJ & 0x100) != 0) ? 3 : 0;
     double bt = 0.0;
     if (c.marginalise_b != 0 && !c.woodbury && bI == bJ) {
 #pragma unroll
@@ -432,6 +435,67 @@ __device__ __forceinline__ int gpcc_fold_mode(const GpccCtx &c, int fI, int fJ, 
     bt_out = bt;
     if (sizeof(T) == 4 && c.asm32 && bt == 0.0) return 2;
     return (c.kernel_id != 1 && (fI & fJ & 0x100) != 0) ? 1 : 0;
+}
+
+// the B term of a row's band (0 for padding): sigma_b[br] without a dynamic index into the kernel argument
+__device__ __forceinline__ double gpcc_fold_bterm(const GpccCtx &c, int br)
+{
+    double bt = 0.0;
+    if (c.marginalise_b != 0 && !c.woodbury) {
+#pragma unroll
+        for (int l = 0; l < GPCC_MAXL; ++l) bt = (br == l) ? c.sigma_b[l] : bt;
+    }
+    return bt;
+}
+// an element of a tile that is NOT inside one band pair (mode 3): gpcc_assemble_tiles' general path for an off-diagonal tile
+template <int KID>
+__device__ __forceinline__ double gpcc_fold_mixed(double ui, double uj, double Ai, double Bi, double Aj, double Bj, double s, int br, int bc,
+                                                  double bterm)
+{
+#pragma clang fp contract(off)   /* the assembly adds the B term to the ROUNDED element (its diagonal select sits in between) */
+    double val = gpcc_sep_eval<KID>(ui, uj, Ai, Bi, Aj, Bj, s);
+    if (br == bc) val = val + bterm;
+    if (br < 0 || bc < 0) val = 0.0;
+    return val;
+}
+template <int KID, typename T, typename ACC>
+__device__ __forceinline__ void gpcc_fold_init_mixed(ACC (&acc)[8], double ui, double Ai, double Bi, const double *cu, const double *cA,
+                                                     const double *cB, double s, int br, double bterm, const int *cb, int q)
+{
+    typedef GpccPrec<T> P;
+#pragma unroll
+    for (int cf = 0; cf < 8; ++cf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = cf * 16 + P::crow(q, r);
+            acc[cf][r] = -(T)gpcc_fold_mixed<KID>(ui, cu[j], Ai, Bi, cA[j], cB[j], s, br, cb[j], bterm);
+        }
+}
+template <int KID, typename T, typename ACC>
+__device__ __forceinline__ void gpcc_fold_init_pu_mixed(ACC (&acc)[2][4], const double *rp, const double *cp, long Np, double s, const GpccCtx &c,
+                                                        const int *rb, const int *cb, int q)
+{
+    typedef GpccPrec<T> P;
+    double uj[4], Aj[4], Bj[4];
+    int bj[4];
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) {
+        uj[fn] = cp[fn * 16];
+        Aj[fn] = cp[Np + fn * 16];
+        Bj[fn] = cp[2 * Np + fn * 16];
+        bj[fn] = cb[fn * 16];
+    }
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = fm * 16 + P::crow(q, r);
+            const double ui = rp[i], Ai = rp[Np + i], Bi = rp[2 * Np + i];
+            const int br = rb[i];
+            const double bterm = gpcc_fold_bterm(c, br);
+#pragma unroll
+            for (int fn = 0; fn < 4; ++fn) acc[fm][fn][r] = -(T)gpcc_fold_mixed<KID>(ui, uj[fn], Ai, Bi, Aj[fn], Bj[fn], s, br, bj[fn], bterm);
+        }
 }
 
 // the accumulators of tile (I,k) from the separable factors (gpcc_update_solve, fold): acc[cf][r'] = -K[row][16 cf + crow(q, r')],
@@ -813,7 +877,7 @@ __device__ __forceinline__ void gpcc_dma_chunk(const T *gA, const T *gB, T *stag
 // part (RIGHT only; look-ahead, round 4): 0 = every trailing tile; 1 = the tiles of column k + 1 only -- what the diagonal step and the
 // panel solve of column k + 1 wait for; 2 = all the others (I >= J >= k + 2), which then run BESIDE that diagonal step on another
 // stream.  A tile's arithmetic is the same in every part.
-template <typename T, bool RIGHT>
+template <typename T, bool RIGHT, bool MIXED = false>
 __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup g, int k, int ktiles, int kcol, int part)
 {
     typedef GpccPrec<T> P;
@@ -887,6 +951,11 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
             else if (c.kernel_id == 1) gpcc_fold_init_pu<1, 2, T>(acc, rp, cp, Np, s, bt, c1, c2, q);
             else if (c.kernel_id == 2) gpcc_fold_init_pu<2, 2, T>(acc, rp, cp, Np, s, bt, c1, c2, q);
             else gpcc_fold_init_pu<3, 2, T>(acc, rp, cp, Np, s, bt, c1, c2, q);
+        } else if (MIXED && fmode == 3) {
+            const int *rb = c.band + I * GPCC_TILE + wr * 32, *cb = c.band + J * GPCC_TILE + wc * 64 + lr;
+            if (c.kernel_id == 0) gpcc_fold_init_pu_mixed<0, T>(acc, rp, cp, Np, s, c, rb, cb, q);
+            else if (c.kernel_id == 2) gpcc_fold_init_pu_mixed<2, T>(acc, rp, cp, Np, s, c, rb, cb, q);
+            else gpcc_fold_init_pu_mixed<3, T>(acc, rp, cp, Np, s, c, rb, cb, q);
         } else {
             if (c.kernel_id == 0) gpcc_fold_init_pu<0, 1, T>(acc, rp, cp, Np, s, bt, c1, c2, q);
             else if (c.kernel_id == 2) gpcc_fold_init_pu<2, 1, T>(acc, rp, cp, Np, s, bt, c1, c2, q);
@@ -973,7 +1042,7 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
 // ------------------------------------------------------------------------------------------
 #define GPCC_UPSOLVE_LDS_BYTES (80 * 1024)
 // one job: tile (I,k) of evaluation `slot` (the whole workgroup; smem = GPCC_UPSOLVE_LDS_BYTES of LDS)
-template <typename T, bool SOLVE>
+template <typename T, bool SOLVE, bool MIXED = false>
 __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const int k, const int I, const int slot, T *smem)
 {
     typedef GpccPrec<T> P;
@@ -1021,6 +1090,16 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
             else if (c.kernel_id == 1) gpcc_fold_init_f32<1, T>(acc, ui, ai, cu, acol, c1, c2, q);
             else if (c.kernel_id == 2) gpcc_fold_init_f32<2, T>(acc, ui, ai, cu, acol, c1, c2, q);
             else gpcc_fold_init_f32<3, T>(acc, ui, ai, cu, acol, c1, c2, q);
+        } else if (MIXED && fmode == 3) {
+            const double s = c.seps[4 * (long)slot];
+            const double Ai = sp[c.Np + ri], Bi = sp[2 * (long)c.Np + ri];
+            const double *cA = cu + c.Np, *cB = cA + c.Np;
+            const int br = c.band[ri];
+            const double bterm = gpcc_fold_bterm(c, br);
+            const int *cb = c.band + k * GPCC_TILE;
+            if (c.kernel_id == 0) gpcc_fold_init_mixed<0, T>(acc, ui, Ai, Bi, cu, cA, cB, s, br, bterm, cb, q);
+            else if (c.kernel_id == 2) gpcc_fold_init_mixed<2, T>(acc, ui, Ai, Bi, cu, cA, cB, s, br, bterm, cb, q);
+            else gpcc_fold_init_mixed<3, T>(acc, ui, Ai, Bi, cu, cA, cB, s, br, bterm, cb, q);
         } else {
             const double s = c.seps[4 * (long)slot];
             const double Ai = sp[c.Np + ri], Bi = sp[2 * (long)c.Np + ri];
@@ -1169,7 +1248,7 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
     }
 }
 
-template <typename T, bool SOLVE>
+template <typename T, bool SOLVE, bool MIXED = false>
 __global__ __launch_bounds__(512, 4) void gpcc_update_solve(GpccCtx c, GpccGroup g, int k)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1182,7 +1261,7 @@ __global__ __launch_bounds__(512, 4) void gpcc_update_solve(GpccCtx c, GpccGroup
 #if !defined(GPCC_TIMING_NO_DMA) && !defined(GPCC_TIMING_NO_LDSREAD) && !defined(GPCC_TIMING_NO_BARRIER)   /* (timing-only builds keep going on garbage) */
     if (c.info[slot] != 0) return;
 #endif
-    gpcc_update_solve_job<T, SOLVE>(c, k, I, slot, (T *)smem_raw);
+    gpcc_update_solve_job<T, SOLVE, MIXED>(c, k, I, slot, (T *)smem_raw);
 }
 
 // ------------------------------------------------------------------------------------------
