@@ -465,10 +465,18 @@ def main():
             if not small:   # the HBM-bound assembly kernel, reported beside it
                 an, ams = prof["assemble"]
                 nt = (N + TILE - 1) // TILE
-                abytes = (8.0 if args.precision == "fp64" else 4.0) * TILE * TILE * nt * (nt + 1) / 2 * G / max(an, 1)
+                esz = 8.0 if args.precision == "fp64" else 4.0
+                # fold_assembly: the factorisation evaluates the off-diagonal tiles itself; what the assembly launches
+                # still write is the diagonal tiles (+ tile column 0 on the three-kernel path) and 4 N doubles of per-point factors
+                folded = (obj.get_option("fold_assembly") == 1 and nt > 1 and G > obj.get_option("fused_small_max")
+                          and (args.kernel != "rbf" or (args.precision == "fp32" and obj.get_option("fp32_assemble") == 1)))
+                tiles_written = (nt + (0 if fused or one_launch else nt - 1)) if folded else nt * (nt + 1) / 2
+                abytes = (esz * TILE * TILE * tiles_written + (32.0 * N if folded else 0.0)) * G / max(an, 1)
                 roofline["assemble"] = {"bound": "hbm", "achieved": round(abytes / (ams / max(an, 1) * 1e-3) / 1e9, 1),
                                         "peak": 8000.0, "unit": "GB/s", "avg_launch_ms": round(ams / max(an, 1), 4),
-                                        "algorithmic_bytes_per_launch": abytes}
+                                        "algorithmic_bytes_per_launch": abytes, "folded_into_factorisation": bool(folded),
+                                        "tiles_written_per_evaluation": tiles_written,
+                                        "launches_counted": "gpcc_sep_points + gpcc_assemble_tiles" if folded else "gpcc_assemble_tiles"}
             else:
                 # what the fp64 pipe EXECUTES per evaluation beside the algorithmic N^3/3 + N^2: padded MFMA blocks,
                 # the element code (exp) and the 16 x 16 pivot steps, all on the same double-precision pipe
