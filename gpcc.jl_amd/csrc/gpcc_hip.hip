@@ -784,16 +784,16 @@ static int enqueue_group(gpcc_handle_t h, const GpccCtx &c_in, const GpccGroup &
     GpccCtx c = c_in;
     // fold: on the fused path every off-diagonal tile (I,k) is read exactly once, by the job that updates and solves it -- which can
     // evaluate the elements itself (gpcc_update_solve); only what the flags of gpcc_sep_points exclude is still assembled
-    // (rbf is not separable: only its fp32 tiles evaluated in fp32 can be folded)
+    // (rbf is not separable: its tiles are folded with the direct evaluation -- or the fp32 one --, through the general instantiations)
     c.fold = 0;
-    if (factor && !ext && h->fold_assembly && (c.kernel_id != 1 || (single && c.asm32)) && c.sep && c.nt > 1 && !c.share_p &&
-        c.nt_fact == c.nt && !c.store_l) {
+    if (factor && !ext && h->fold_assembly && c.sep && c.nt > 1 && !c.share_p && c.nt_fact == c.nt && !c.store_l) {
         const bool right = g.cnt <= h->right_looking_max;
         if (takes_fused_solve(h, c, g.cnt)) c.fold = 1;
         else if (!(right && g.cnt <= h->fused_small_max) && !h->update_t) c.fold = 2;   // (not the gpcc_small_step path of a few evaluations)
         // tile rows that straddle two bands or hold padding: the MIXED instantiations (a handle without such rows keeps the leaner ones;
         // gpcc_step has no MIXED form)
-        c.fold_mixed = (c.fold && h->mixed_rows && !(c.fold == 1 && h->step_fused)) ? 1 : 0;
+        c.fold_mixed = (c.fold && (h->mixed_rows || c.kernel_id == 1) && !(c.fold == 1 && h->step_fused)) ? 1 : 0;
+        if (c.kernel_id == 1 && !c.fold_mixed && !(single && c.asm32)) c.fold = 0;   // (rbf with gpcc_step: nothing to fold in fp64)
     }
     if (c.fold) {
         ProfScope p(h, GPCC_PROF_ASSEMBLE, s);

@@ -83,8 +83,9 @@ struct GpccCtx {
     int fold;        // 1: the off-diagonal tiles inside one band pair are NOT assembled -- gpcc_update_solve evaluates their elements
                      //    into its accumulators (fused left-looking groups; which tiles: gpcc_fold_mode);
                      // 2: the three-kernel path: likewise for tile columns J >= 1, in the first gpcc_panel_update job that touches the tile
-    int fold_mixed;  // 1: ... also the tiles of a tile row that straddles two bands or holds padding (gpcc_fold_mode 3; the MIXED
-                     //    instantiations of the two kernels: the host launches those when it sets this)
+    int fold_mixed;  // 1: ... also the tiles of a tile row that straddles two bands or holds padding (gpcc_fold_mode 3) and tiles that
+                     //    need the direct evaluation (mode 4: rbf) -- the MIXED ("general") instantiations of the two kernels: the host
+                     //    launches those when it sets this (handles with such tile rows, rbf handles)
     const double *t, *sig2, *resid;  // Np (padding: 0)
     const double *yv;                // Np: raw fluxes (only read by explicit 'Y' rows, see band codes)
     const int *band;                 // Np: >= 0 band of a real point; -1 identity padding;
@@ -419,7 +420,9 @@ __global__ __launch_bounds__(GPCC_TILE) void gpcc_sep_points(GpccCtx c, GpccGrou
 // gpcc_assemble_tiles and read back (points outside the separable range; rbf in fp64 or in a tile row that straddles bands; rbf in
 // fp64), 1 = the separable form in fp64, rounded once for fp32 tiles, 2 = fp32 tiles evaluated in fp32 (GpccCtx::asm32; needs no B
 // term), 3 = a tile row that straddles two bands or holds padding: the separable form with the B term and the padding decided per
-// element (gpcc_assemble_tiles' general path).  The SAME case distinction as in gpcc_assemble_tiles, so that folded and assembled
+// element (gpcc_assemble_tiles' general path), 4 = a tile inside one band pair that cannot take the separable form (rbf; points outside
+// the range): the direct evaluation with its exponential, as the assembly's select-free path does it (28 operations per element: ~2 % of
+// the job's matrix work, still cheaper than writing the tile and reading it back).  The SAME case distinction as in gpcc_assemble_tiles, so that folded and assembled
 // tiles agree bitwise.  bt_out: the B term of a tile inside one band pair.
 template <typename T>
 __device__ __forceinline__ int gpcc_fold_mode(const GpccCtx &c, int fI, int fJ, double &bt_out)
@@ -434,7 +437,41 @@ __device__ __forceinline__ int gpcc_fold_mode(const GpccCtx &c, int fI, int fJ, 
     }
     bt_out = bt;
     if (sizeof(T) == 4 && c.asm32 && bt == 0.0) return 2;
-    return (c.kernel_id != 1 && (fI & fJ & 0x100) != 0) ? 1 : 0;
+    if (c.kernel_id != 1 && (fI & fJ & 0x100) != 0) return 1;
+    return c.fold_mixed ? 4 : 0;   // (the general instantiations only: the host launches those for every rbf handle)
+}
+
+// mode 4: amp * kernel(|u_i - u_j| * kscale) + bt, exactly gpcc_assemble_tiles' select-free direct path
+template <int KID, typename T, typename ACC>
+__device__ __forceinline__ void gpcc_fold_init_direct(ACC (&acc)[8], double ui, double ai, const double *cu, double acol, double kscale, double bt, int q)
+{
+    typedef GpccPrec<T> P;
+    const double amp = ai * acol;
+#pragma unroll
+    for (int cf = 0; cf < 8; ++cf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = cf * 16 + P::crow(q, r);
+            acc[cf][r] = -(T)(amp * gpcc_kernel_eval_scaled<KID>(ui, cu[j], kscale) + bt);
+        }
+}
+template <int KID, typename T, typename ACC>
+__device__ __forceinline__ void gpcc_fold_init_pu_direct(ACC (&acc)[2][4], const double *rp, const double *cp, long Np, double kscale, double bt, int q)
+{
+    typedef GpccPrec<T> P;
+    double uj[4];
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) uj[fn] = cp[fn * 16];
+    const double acol = cp[3 * Np];
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = fm * 16 + P::crow(q, r);
+            const double ui = rp[i], amp = rp[3 * Np + i] * acol;
+#pragma unroll
+            for (int fn = 0; fn < 4; ++fn) acc[fm][fn][r] = -(T)(amp * gpcc_kernel_eval_scaled<KID>(ui, uj[fn], kscale) + bt);
+        }
 }
 
 // the B term of a row's band (0 for padding): sigma_b[br] without a dynamic index into the kernel argument
@@ -951,6 +988,11 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
             else if (c.kernel_id == 1) gpcc_fold_init_pu<1, 2, T>(acc, rp, cp, Np, s, bt, c1, c2, q);
             else if (c.kernel_id == 2) gpcc_fold_init_pu<2, 2, T>(acc, rp, cp, Np, s, bt, c1, c2, q);
             else gpcc_fold_init_pu<3, 2, T>(acc, rp, cp, Np, s, bt, c1, c2, q);
+        } else if (MIXED && fmode == 4) {
+            if (c.kernel_id == 0) gpcc_fold_init_pu_direct<0, T>(acc, rp, cp, Np, s, bt, q);
+            else if (c.kernel_id == 1) gpcc_fold_init_pu_direct<1, T>(acc, rp, cp, Np, s, bt, q);
+            else if (c.kernel_id == 2) gpcc_fold_init_pu_direct<2, T>(acc, rp, cp, Np, s, bt, q);
+            else gpcc_fold_init_pu_direct<3, T>(acc, rp, cp, Np, s, bt, q);
         } else if (MIXED && fmode == 3) {
             const int *rb = c.band + I * GPCC_TILE + wr * 32, *cb = c.band + J * GPCC_TILE + wc * 64 + lr;
             if (c.kernel_id == 0) gpcc_fold_init_pu_mixed<0, T>(acc, rp, cp, Np, s, c, rb, cb, q);
@@ -1090,6 +1132,13 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
             else if (c.kernel_id == 1) gpcc_fold_init_f32<1, T>(acc, ui, ai, cu, acol, c1, c2, q);
             else if (c.kernel_id == 2) gpcc_fold_init_f32<2, T>(acc, ui, ai, cu, acol, c1, c2, q);
             else gpcc_fold_init_f32<3, T>(acc, ui, ai, cu, acol, c1, c2, q);
+        } else if (MIXED && fmode == 4) {
+            const double s = c.seps[4 * (long)slot];   // (gpcc_kernel_scale: also the scale of the direct form)
+            const double ai = sp[3 * (long)c.Np + ri], acol = cu[3 * (long)c.Np];
+            if (c.kernel_id == 0) gpcc_fold_init_direct<0, T>(acc, ui, ai, cu, acol, s, bt, q);
+            else if (c.kernel_id == 1) gpcc_fold_init_direct<1, T>(acc, ui, ai, cu, acol, s, bt, q);
+            else if (c.kernel_id == 2) gpcc_fold_init_direct<2, T>(acc, ui, ai, cu, acol, s, bt, q);
+            else gpcc_fold_init_direct<3, T>(acc, ui, ai, cu, acol, s, bt, q);
         } else if (MIXED && fmode == 3) {
             const double s = c.seps[4 * (long)slot];
             const double Ai = sp[c.Np + ri], Bi = sp[2 * (long)c.Np + ri];

@@ -105,9 +105,10 @@ int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms
  * k + 1 first, then the rest" and run the diagonal step and panel solve of column k + 1 beside the rest, which goes to a low-priority
  * helper stream -- LAPACK's look-ahead where the chain's few workgroups find CUs of their own; bitwise the results of 0.  Measured: the
  * overlap works, the extra launch of single-tile jobs costs what it saves: +1 % for 13-20 evaluations, -2 ... -5 % for 24-64; off),
- * "fold_assembly" (round 4; 1 = default: fp64 groups on the fused_solve path with OU / Matern kernels do not write the off-diagonal
- * tiles of delayedCovariance that lie inside one band pair -- the update kernel evaluates those elements into its accumulators, the
- * same bits gpcc_model_matrix returns; 0 = every tile is assembled first, as in rounds 1-3),
+ * "fold_assembly" (round 4; 1 = default: groups of more than fused_small_max evaluations do not write the off-diagonal tiles of
+ * delayedCovariance -- the job of the factorisation that reads a tile first evaluates its elements into its accumulators instead, the
+ * same bits gpcc_model_matrix returns (all four kernels, fp64 and fp32 handles; the diagonal tiles, and tile column 0 on the
+ * three-kernel path, are still assembled); 0 = every tile is assembled first, as in rounds 1-3),
  * "shared_prefix" (0 off; 1 = default: gpcc_loglik_batch detects a
  * batch whose evaluations all have the same band-1 amplitude, delay and rho -- a fixed-hyper-parameter delay
  * sweep, README.md:172-174 -- and then factorises the tile rows wholly inside band 1 once per group instead of
