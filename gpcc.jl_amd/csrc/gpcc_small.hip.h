@@ -42,7 +42,13 @@
 #define GPCC_SMALL_DLD 17
 // blocks per staging pass of a row's elements (2 KiB each): half a row up to NB = 8, three blocks beyond -- NB = 9 and 10 then
 // stay within 20 KiB of LDS per wave, i.e. eight waves (two per SIMD) per CU
+// (round 4: ONE block per pass up to NB = 7 -- 13.1 KiB of LDS per wave, so that twelve waves (three per SIMD) fit a CU; the staging
+// only exists to keep the element loop rolled, its depth changes no arithmetic)
+#ifdef GPCC_AB_SMALL_WPE2   /* A/B builds only (tools/ab_small.sh): two waves per SIMD for NB = 5 .. 7, as in round 3 */
 #define GPCC_SMALL_SB(NB) ((NB) <= 8 ? ((NB) + 1) / 2 : ((NB) <= 10 ? 3 : ((NB) + 1) / 2))
+#else
+#define GPCC_SMALL_SB(NB) ((NB) <= 7 ? 1 : (NB) <= 8 ? ((NB) + 1) / 2 : ((NB) <= 10 ? 3 : ((NB) + 1) / 2))
+#endif
 
 __device__ __forceinline__ void gpcc_small_potf2(const double *sD, double *sX, double *sr, const int lane, const bool last,
                                                  const int base, double &py, int &pe, int &bad, double &quad)

@@ -11,7 +11,7 @@
 constexpr int KID = GPCC_INST_KID;
 
 #if !GPCC_INST_WIDE
-// one wave per evaluation: every block count 1 .. 12 (N <= 191); four waves per SIMD up to NB = 3, two up to NB = 10 (NB = 9, 10 with a
+// one wave per evaluation: every block count 1 .. 12 (N <= 191); four waves per SIMD up to NB = 3, three up to NB = 7, two up to NB = 10 (NB = 9, 10 with a
 // few dozen scratch accesses: measured 14.7 -> 20.0 M evaluations/s at N = 128, 12.3 -> 15.4 M/s at N = 150; NB = 11, 12: no gain), one beyond
 hipError_t GPCC_CAT(gpcc_small_launch_, GPCC_INST_KID)(int nb, const GpccCtx &c, const GpccGroup &g, hipStream_t s)
 {
@@ -20,9 +20,17 @@ hipError_t GPCC_CAT(gpcc_small_launch_, GPCC_INST_KID)(int nb, const GpccCtx &c,
     case 2: gpcc_small_eval<2, KID, 4><<<g.cnt, 64, 0, s>>>(c, g); break;
     case 3: gpcc_small_eval<3, KID, 4><<<g.cnt, 64, 0, s>>>(c, g); break;
     case 4: gpcc_small_eval<4, KID, 2><<<g.cnt, 64, 0, s>>>(c, g); break;
+#ifdef GPCC_AB_SMALL_WPE2
     case 5: gpcc_small_eval<5, KID, 2><<<g.cnt, 64, 0, s>>>(c, g); break;
     case 6: gpcc_small_eval<6, KID, 2><<<g.cnt, 64, 0, s>>>(c, g); break;
     case 7: gpcc_small_eval<7, KID, 2><<<g.cnt, 64, 0, s>>>(c, g); break;
+#else
+    // three waves per SIMD (round 4): the two waves of round 3 both sat in a pivot chain 0.36 of the time (small_pmc_summary.json);
+    // <= 168 registers costs NB = 7 23 spilled registers (NB = 5, 6: none): N = 110 33.5 -> 37.1 M evaluations/s, N = 94 +14 %, N = 78 +14 %
+    case 5: gpcc_small_eval<5, KID, 3><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 6: gpcc_small_eval<6, KID, 3><<<g.cnt, 64, 0, s>>>(c, g); break;
+    case 7: gpcc_small_eval<7, KID, 3><<<g.cnt, 64, 0, s>>>(c, g); break;
+#endif
     case 8: gpcc_small_eval<8, KID, 2><<<g.cnt, 64, 0, s>>>(c, g); break;
     case 9: gpcc_small_eval<9, KID, 2><<<g.cnt, 64, 0, s>>>(c, g); break;
     case 10: gpcc_small_eval<10, KID, 2><<<g.cnt, 64, 0, s>>>(c, g); break;
