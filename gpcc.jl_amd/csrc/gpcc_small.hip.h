@@ -50,6 +50,12 @@
 #define GPCC_SMALL_SB(NB) ((NB) <= 7 ? 1 : (NB) <= 8 ? ((NB) + 1) / 2 : ((NB) <= 10 ? 3 : ((NB) + 1) / 2))
 #endif
 
+#ifdef GPCC_AB_SMALL_LEAN_OFF   /* A/B builds only */
+#define GPCC_SMALL_LEAN(NB) false
+#else
+#define GPCC_SMALL_LEAN(NB) ((NB) == 9 || (NB) == 10)
+#endif
+
 __device__ __forceinline__ void gpcc_small_potf2(const double *sD, double *sX, double *sr, const int lane, const bool last,
                                                  const int base, double &py, int &pe, int &bad, double &quad)
 {
@@ -198,6 +204,60 @@ __device__ __forceinline__ void gpcc_small_rows(d4 (&U)[NB][NB], GpccSmallState 
         constexpr int NP = 16 * NB, DLD = GPCC_SMALL_DLD;
         constexpr int SB = GPCC_SMALL_SB(NB);   // blocks per staging pass
         const int lane = st.lane, lr = lane & 15, q = lane >> 4;
+        if constexpr (GPCC_SMALL_LEAN(NB)) {
+            // Block-at-a-time form (round 4; NB = 9, 10, where the row-at-a-time form below spills 37 / 147 registers): the blocks of row J
+            // stay in the LDS stage until they are consumed, ONE of them in registers at a time -- the diagonal block first (update,
+            // 16 x 16 step), then block by block: update, times -inv(L_D).  Per block the same operations in the same order.
+            double ax[4];
+#pragma unroll
+            for (int i0 = J; i0 < NB; i0 += SB) {
+                const int i1 = (i0 + SB < NB) ? i0 + SB : NB;
+#pragma nounroll
+                for (int i = i0; i < i1; ++i) {
+                    double val[4];
+                    gpcc_small_block<KID, NP>(st, J, i, val);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st.sstage[((i - i0) * 4 + r) * 64 + lane] = -val[r];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = i0; i < i1; ++i) {
+                    d4 Ti;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Ti[r] = st.sstage[((i - i0) * 4 + r) * 64 + lane];
+#pragma unroll
+                    for (int mm = 0; mm < J; ++mm)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) Ti = PD::mfma(U[mm][J][s], U[mm][i][s], Ti);
+                    if (i == J) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) st.sD[(q + 4 * r) * DLD + lr] = -Ti[r];
+                        __syncthreads();
+                        __builtin_amdgcn_sched_barrier(0);
+                        gpcc_small_potf2(st.sD, st.sX, st.sr, lane, J == NB - 1, 16 * J, st.py, st.pe, st.bad, st.quad);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (st.bad) return;
+                        if constexpr (J < NB - 1) {
+                            __syncthreads();
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) ax[s] = st.sX[lr * DLD + q + 4 * s];
+                        }
+                    } else {
+                        d4 o = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) o = PD::mfma(ax[s], Ti[s], o);
+                        U[J][i] = o;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (J < NB - 1) {
+                __syncthreads();   // sD / sX are rewritten by the next row
+                __builtin_amdgcn_sched_barrier(0);
+                gpcc_small_rows<NB, KID, J + 1>(U, st);
+            }
+            return;
+        }
         d4 T[NB];
         // ---- (a) row J of S = -(K bordered): blocks (J, i), i >= J, through the LDS stage
 #pragma unroll
