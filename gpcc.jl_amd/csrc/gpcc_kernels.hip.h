@@ -1107,6 +1107,19 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
     // (Measured and dropped in round 4: ONE barrier per TWO chunks -- the B operand is a wave's own rows and needs no barrier, the A
     // operand in a ring of four stages filled a pair ahead, 64 MFMAs per wave between barriers: correct, and not a percent faster
     // (fp32 -1 %).  What the timing-only "no barrier" build gains is waves running free of each other, not the barriers' own cost.)
+    // The per-point vectors of tile column k that the fold evaluates from (u, A, B, a: 1 KiB each; the band ids) and w_k of the forward
+    // substitution go to the 8 KiB of LDS above the inverse's 72 KiB by LDS-DMA, one piece per wave, BEFORE the first chunk's pieces:
+    // read from global memory, a lane's 96 loads of 8 bytes went out in register-limited batches, each a full memory latency --
+    // the timing-only build without the initialisation was 7.8 % faster (N = 2048: 16 %), profiles/r04/timing_only_job_fixed_cost.log
+    constexpr int VEC_OFF = 72 * 1024;
+    const bool staged = SOLVE && c.fold != 0;   // (uniform)
+    if (staged) {
+        const double *spk = c.sep + (long)slot * 4 * c.Np + k * GPCC_TILE;
+        if (wave < 4) gpcc_dma_piece<0>(gpcc_uniform_ptr(spk + (long)wave * c.Np), (unsigned)lane * 16u, smem_addr + VEC_OFF + wave * 1024);
+        else if (wave == 4) gpcc_dma_piece<0>(gpcc_uniform_ptr(c.band + k * GPCC_TILE), (unsigned)lane * 16u, smem_addr + VEC_OFF + 4096);
+        else if (wave == 5) gpcc_dma_piece<0>(gpcc_uniform_ptr(c.w + (long)slot * c.nrhs * c.Np + k * GPCC_TILE), (unsigned)lane * 16u, smem_addr + VEC_OFF + 5120);
+    }
+    const double *vec = (const double *)((const char *)smem + VEC_OFF);   // u | A | B | a | band (int, 512 B; 512 B unused) | w_k of rhs 0
     if (nch > 0) gpcc_dma_chunk_at<T>(gI, gK, smem_addr, wave, lane);
     const T *pb0 = smem + (wave * 16 + lr) * P::KC + (((2 * q) ^ sw) * P::EP);        // stage: [row I chunk | row k chunk]
     const T *pb1 = smem + (wave * 16 + lr) * P::KC + (((2 * q + 1) ^ sw) * P::EP);
@@ -1117,42 +1130,48 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
     // operations per element = 0.5 % of the job's matrix work at the mean k, under the first chunk's LDS-DMA
     int fmode = 0;
     double bt = 0.0;
+#ifdef GPCC_TIMING_NO_INIT   /* timing-only: accumulators start at zero (WRONG results) */
+#pragma unroll
+    for (int cf = 0; cf < 8; ++cf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[cf][r] = 0;
+    if (false)
+#else
     if (SOLVE && c.fold)
+#endif
         fmode = gpcc_fold_mode<T>(c, __builtin_amdgcn_readfirstlane(c.sepflag[(long)slot * c.nt + I]),
                                   __builtin_amdgcn_readfirstlane(c.sepflag[(long)slot * c.nt + k]), bt);
     if (SOLVE && fmode != 0) {
         const double *sp = c.sep + (long)slot * 4 * c.Np;
         const int ri = I * GPCC_TILE + wave * 16 + lr;
-        const double ui = sp[ri];
-        const double *cu = sp + k * GPCC_TILE;
+        // (this lane's row: four coalesced loads, issued before the wait)
+        const double ui = sp[ri], Ai = sp[c.Np + ri], Bi = sp[2 * (long)c.Np + ri], ai = sp[3 * (long)c.Np + ri];
+        const int br = MIXED ? c.band[ri] : 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the vectors (and, as it happens, the first chunk) have landed
+        __syncthreads();
+        const double *cu = vec, *cA = vec + GPCC_TILE, *cB = vec + 2 * GPCC_TILE;   // (LDS)
+        const double acol = vec[3 * GPCC_TILE];
+        const int *cb = (const int *)(vec + 4 * GPCC_TILE);
         if (sizeof(T) == 4 && fmode == 2) {
-            const float ai = (float)sp[3 * (long)c.Np + ri], acol = (float)cu[3 * (long)c.Np];
             const float c1 = (float)c.seps[4 * (long)slot + 1], c2 = (float)c.seps[4 * (long)slot + 2];
-            if (c.kernel_id == 0) gpcc_fold_init_f32<0, T>(acc, ui, ai, cu, acol, c1, c2, q);
-            else if (c.kernel_id == 1) gpcc_fold_init_f32<1, T>(acc, ui, ai, cu, acol, c1, c2, q);
-            else if (c.kernel_id == 2) gpcc_fold_init_f32<2, T>(acc, ui, ai, cu, acol, c1, c2, q);
-            else gpcc_fold_init_f32<3, T>(acc, ui, ai, cu, acol, c1, c2, q);
+            if (c.kernel_id == 0) gpcc_fold_init_f32<0, T>(acc, ui, (float)ai, cu, (float)acol, c1, c2, q);
+            else if (c.kernel_id == 1) gpcc_fold_init_f32<1, T>(acc, ui, (float)ai, cu, (float)acol, c1, c2, q);
+            else if (c.kernel_id == 2) gpcc_fold_init_f32<2, T>(acc, ui, (float)ai, cu, (float)acol, c1, c2, q);
+            else gpcc_fold_init_f32<3, T>(acc, ui, (float)ai, cu, (float)acol, c1, c2, q);
         } else if (MIXED && fmode == 4) {
             const double s = c.seps[4 * (long)slot];   // (gpcc_kernel_scale: also the scale of the direct form)
-            const double ai = sp[3 * (long)c.Np + ri], acol = cu[3 * (long)c.Np];
             if (c.kernel_id == 0) gpcc_fold_init_direct<0, T>(acc, ui, ai, cu, acol, s, bt, q);
             else if (c.kernel_id == 1) gpcc_fold_init_direct<1, T>(acc, ui, ai, cu, acol, s, bt, q);
             else if (c.kernel_id == 2) gpcc_fold_init_direct<2, T>(acc, ui, ai, cu, acol, s, bt, q);
             else gpcc_fold_init_direct<3, T>(acc, ui, ai, cu, acol, s, bt, q);
         } else if (MIXED && fmode == 3) {
             const double s = c.seps[4 * (long)slot];
-            const double Ai = sp[c.Np + ri], Bi = sp[2 * (long)c.Np + ri];
-            const double *cA = cu + c.Np, *cB = cA + c.Np;
-            const int br = c.band[ri];
             const double bterm = gpcc_fold_bterm(c, br);
-            const int *cb = c.band + k * GPCC_TILE;
             if (c.kernel_id == 0) gpcc_fold_init_mixed<0, T>(acc, ui, Ai, Bi, cu, cA, cB, s, br, bterm, cb, q);
             else if (c.kernel_id == 2) gpcc_fold_init_mixed<2, T>(acc, ui, Ai, Bi, cu, cA, cB, s, br, bterm, cb, q);
             else gpcc_fold_init_mixed<3, T>(acc, ui, Ai, Bi, cu, cA, cB, s, br, bterm, cb, q);
         } else {
             const double s = c.seps[4 * (long)slot];
-            const double Ai = sp[c.Np + ri], Bi = sp[2 * (long)c.Np + ri];
-            const double *cA = cu + c.Np, *cB = cA + c.Np;
             if (c.kernel_id == 0) gpcc_fold_init<0, T>(acc, ui, Ai, Bi, cu, cA, cB, s, bt, q);
             else if (c.kernel_id == 2) gpcc_fold_init<2, T>(acc, ui, Ai, Bi, cu, cA, cB, s, bt, q);
             else gpcc_fold_init<3, T>(acc, ui, Ai, Bi, cu, cA, cB, s, bt, q);
@@ -1200,7 +1219,11 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
         }
     }
 #endif
+#ifdef GPCC_TIMING_NO_SOLVE    /* timing-only diagnostic builds (tools/timing_variants2.sh): WRONG results, never shipped */
+    if (SOLVE && c.nt < 0) {
+#else
     if (SOLVE) {
+#endif
         // ---- lower blocks of X = inv(L_kk) -> LDS, packed chunk by chunk: chunk ch2 of the tile holds columns KC ch2 .. of all
         // 128 rows; rows above the chunk's first column block are zero and skipped.  Block (i, cf) is then read at
         // xbase(cf) + rows 16 i ..: element (R, col) at xoff[chunk] + (R - R0[chunk]) KC + swizzled slot.
@@ -1215,12 +1238,14 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
                 o += (GPCC_TILE - 16 * FPC * ch) * P::KC;     // rows 16 FPC ch .. 127
             }
         }
+#ifndef GPCC_TIMING_NO_XLOAD
 #pragma unroll
         for (int ch = 0; ch < P::NCH; ++ch) {
             const int r0x = 16 * FPC * ch, npiece = (GPCC_TILE - r0x) * P::KC / PIECE;   // 1 KiB pieces of this chunk's lower rows
             for (int pc = __builtin_amdgcn_readfirstlane(wave); pc < npiece; pc += 8)
                 gpcc_dma_piece<0>(gpcc_uniform_ptr(gX + (long)ch * CH + r0x * P::KC + pc * PIECE), (unsigned)lane * 16u, gpcc_lds_addr(smem + xoff[ch] + pc * PIECE));
         }
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         auto xload = [&](int i, int cf, T (&xa)[4]) {   // A operand of block (i, cf): X[16 i + lr][16 cf + crow(q, s2)], s2 = 0..3
@@ -1254,6 +1279,9 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
         }
         __syncthreads();   // every wave is done with X before the output staging overwrites it
     }
+#ifdef GPCC_TIMING_NO_STORE
+    if (c.nt >= 0) return;   // (timing-only: the compiler cannot drop the arithmetic, the job skips its output)
+#endif
     // ---- out through LDS in the tile's own byte layout (rows 64 h .. 64 h + 63 of every chunk = 64 KiB in fp64), then linear
     // 16-byte copies to global; L = -acc (resp. T' = -acc)
     constexpr int HALVES = (int)(sizeof(T) * GPCC_TILE_ELEMS / 65536);   // fp64: 2, fp32: 1
@@ -1286,10 +1314,18 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
             double *zp = c.z + ((long)slot * c.nrhs + j) * c.Np + I * GPCC_TILE;
             const double *wp = c.w + ((long)slot * c.nrhs + j) * c.Np + k * GPCC_TILE;
             double pr = 0.0;
+            if (staged && j == 0) {   // w_k of the first right-hand side sits in LDS since the job began (same values, same order)
+                const double *wl = vec + 5 * GPCC_TILE;
 #pragma unroll
-            for (int cf = 0; cf < 8; ++cf)
+                for (int cf = 0; cf < 8; ++cf)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pr = fma(-(double)acc[cf][r], wp[cf * 16 + P::crow(q, r)], pr);
+                    for (int r = 0; r < 4; ++r) pr = fma(-(double)acc[cf][r], wl[cf * 16 + P::crow(q, r)], pr);
+            } else {
+#pragma unroll
+                for (int cf = 0; cf < 8; ++cf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pr = fma(-(double)acc[cf][r], wp[cf * 16 + P::crow(q, r)], pr);
+            }
             pr += __shfl_xor(pr, 16);
             pr += __shfl_xor(pr, 32);
             if (q == 0) zp[wave * 16 + lr] -= pr;
@@ -1307,7 +1343,8 @@ __global__ __launch_bounds__(512, 4) void gpcc_update_solve(GpccCtx c, GpccGroup
     if (m >= g.cnt) return;
     const int I = k + (SOLVE ? 1 : 0) + (g.spread ? (int)blockIdx.x / g.cnt : qq % per);
     const int slot = g.slot0 + m;
-#if !defined(GPCC_TIMING_NO_DMA) && !defined(GPCC_TIMING_NO_LDSREAD) && !defined(GPCC_TIMING_NO_BARRIER)   /* (timing-only builds keep going on garbage) */
+#if !defined(GPCC_TIMING_NO_DMA) && !defined(GPCC_TIMING_NO_LDSREAD) && !defined(GPCC_TIMING_NO_BARRIER) && !defined(GPCC_TIMING_NO_XLOAD) && \
+    !defined(GPCC_TIMING_NO_SOLVE) && !defined(GPCC_TIMING_NO_STORE) && !defined(GPCC_TIMING_NO_INIT)   /* (timing-only builds keep going on garbage) */
     if (c.info[slot] != 0) return;
 #endif
     gpcc_update_solve_job<T, SOLVE, MIXED>(c, k, I, slot, (T *)smem_raw);
