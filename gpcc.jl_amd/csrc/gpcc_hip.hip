@@ -124,6 +124,8 @@ struct gpcc_handle_s {
     int update_t = 0;        // diagnostic option "update_t": the three-kernel path with gpcc_update_solve<T, false> as its update (A/B of the transposed main loop)
     int fused_solve_min = 112;   // ... from this group size on (below it the diagonal tile's serial K-loop on ONE CU per evaluation costs
                                  // more than the fused solve saves: measured crossover 96-128 evaluations at N = 1024 and N = 4096)
+    int fused_solve_min_split = 64;   // option "fused_solve_min_split": ... for the two halves of a split group (split_min): 128-160 evaluations at
+                                 // N = 4096 +1.5 ... 2 %, at N = 2048 +4 ... 6 % (profiles/r04/fused_solve_min_sweep_after_fold.log)
     int fused_solve = 1;     // option "fused_solve": left-looking groups run gpcc_syrk_diag + gpcc_update_solve (2 launches per step)
     int look_ahead = 0;      // option "look_ahead": right-looking steps of the three-kernel path update column k + 1 first, then run its diagonal
                              // step and panel solve beside the rest of the trailing update (which goes to a low-priority helper stream); bitwise
@@ -492,6 +494,9 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->update_t = (int)v;
     } else if (!strcmp(key, "fused_solve")) {
         h->fused_solve = v != 0;
+    } else if (!strcmp(key, "fused_solve_min_split")) {
+        if (v < 1) return fail(h, GPCC_ERR_ARGUMENT, "fused_solve_min_split must be >= 1");
+        h->fused_solve_min_split = (int)v;
     } else if (!strcmp(key, "look_ahead")) {
         h->look_ahead = v != 0;
     } else if (!strcmp(key, "fold_assembly")) {
@@ -502,6 +507,9 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->diag_blocks = v != 0;
     } else if (!strcmp(key, "fused_solve_min")) {
         h->fused_solve_min = (int)v;
+        // (the halves of a split group follow: a caller who moves the threshold away from its default range -- to pin a path -- pins
+        //  it for the halves too; "fused_solve_min_split" set afterwards overrides)
+        h->fused_solve_min_split = (v < 64) ? (int)v : (v > 112 ? (int)v : 64);
     } else if (!strcmp(key, "small_n")) {
         h->small_n = v != 0;
     } else if (!strcmp(key, "small_wide_max")) {
@@ -569,6 +577,7 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "precision")) return h->precision;
     if (!strcmp(key, "fused_solve")) return h->fused_solve;
     if (!strcmp(key, "fused_solve_min")) return h->fused_solve_min;
+    if (!strcmp(key, "fused_solve_min_split")) return h->fused_solve_min_split;
     if (!strcmp(key, "look_ahead")) return h->look_ahead;
     if (!strcmp(key, "fold_assembly")) return h->fold_assembly;
     if (!strcmp(key, "step_fused")) return h->step_fused;
@@ -771,10 +780,12 @@ static void launch_assemble(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &
 static int enqueue_factor(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g, hipStream_t s, bool f32, int concurrent);
 
 // the group runs left-looking with the panel solve inside the update (gpcc_syrk_diag + gpcc_update_solve)
-static bool takes_fused_solve(gpcc_handle_t h, const GpccCtx &c, int cnt)
+static bool takes_fused_solve(gpcc_handle_t h, const GpccCtx &c, int cnt, int concurrent)
 {
     const bool right = (cnt <= h->right_looking_max) && (c.nt_fact == c.nt) && !c.share_p;
-    return !right && !c.share_p && c.nt_fact == c.nt && h->fused_solve && cnt >= h->fused_solve_min && !c.store_l;
+    // (the halves of a split group hide each other's serial diagonal-tile loop: the fused path pays from 64 evaluations per half on)
+    const int min_cnt = (concurrent >= 2) ? h->fused_solve_min_split : h->fused_solve_min;
+    return !right && !c.share_p && c.nt_fact == c.nt && h->fused_solve && cnt >= min_cnt && !c.store_l;
 }
 
 static int enqueue_group(gpcc_handle_t h, const GpccCtx &c_in, const GpccGroup &g, hipStream_t s, bool factor = true,
@@ -788,7 +799,7 @@ static int enqueue_group(gpcc_handle_t h, const GpccCtx &c_in, const GpccGroup &
     c.fold = 0;
     if (factor && !ext && h->fold_assembly && c.sep && c.nt > 1 && !c.share_p && c.nt_fact == c.nt && !c.store_l) {
         const bool right = g.cnt <= h->right_looking_max;
-        if (takes_fused_solve(h, c, g.cnt)) c.fold = 1;
+        if (takes_fused_solve(h, c, g.cnt, concurrent)) c.fold = 1;
         else if (!(right && g.cnt <= h->fused_small_max) && !h->update_t) c.fold = 2;   // (not the gpcc_small_step path of a few evaluations)
         // tile rows that straddle two bands or hold padding: the MIXED instantiations (a handle without such rows keeps the leaner ones;
         // gpcc_step has no MIXED form)
@@ -875,7 +886,7 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
         }
         return;
     }
-    if (takes_fused_solve(h, c, g.cnt)) {
+    if (takes_fused_solve(h, c, g.cnt, concurrent)) {
         // left-looking, the panel solve inside the update (gpcc_update_solve): per step the diagonal tile first
         // (gpcc_syrk_diag: lower-triangle update + diagonal step in one workgroup per evaluation), then the rest of column k
         if (h->step_fused && c.nrhs <= GPCC_DB_MAXRHS) {

@@ -94,6 +94,8 @@ int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms
  * "fused_solve" (1 = default: left-looking groups run the panel solve inside the update kernel and the diagonal tile's update
  * inside the diagonal step -- two launches per step; 0 = the three-kernel path of round 1; results agree to ~1e-13),
  * "fused_solve_min" (default 112: groups smaller than this keep the three-kernel path, which is faster there),
+ * "fused_solve_min_split" (round 4, default 64: the same threshold for each half of a group that runs as two halves on two streams;
+ * setting "fused_solve_min" below 64 or above 112 moves this one with it),
  * "step_fused" (round 4; 0 = default; 1: those two launches are ONE -- gpcc_step: the workgroup that owns tile (k+1,k) goes on into the
  * diagonal step of column k+1 while the rest of the launch updates column k, LAPACK's look-ahead; results bitwise those of
  * step_fused = 0), "diag_blocks" (round 4; 0 = default; 1: the diagonal step of the three-kernel path keeps the tile as 36 packed
