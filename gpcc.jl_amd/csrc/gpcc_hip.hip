@@ -148,7 +148,9 @@ struct gpcc_handle_s {
                                 // N = 4096 -- left OFF: the bits of an evaluation would then depend on the size of its group
     int split_min = 24;         // option "split_min": a group of at least this many evaluations (0 = never) runs as TWO halves on two
                                 // streams, so that the update of one half hides the diagonal-step / panel-solve chain of the other ...
-    int split_max = 160;        // option "split_max": ... up to this many (192: -1 ... -3 %; a fused-path group of 256 has no idle chain left to hide) ...
+    int split_max = 240;        // option "split_max": ... up to this many (a full group of 256 has no idle chain left to hide: -1.3 % when split).  Round 3: 160
+                                // (halves on the three-kernel path: 192 was -1 ... -3 %); with fused halves (fused_solve_min_split) 176-224 evaluations gain
+                                // +0.7 ... 1.8 % at N = 4096 and nothing at N = 2048 (profiles/r04/fused_solve_min_sweep_after_fold.log) ...
     int split_nt_min = 12;      // option "split_nt_min": ... at N > 128 * (this - 1) (below, the halves only get in each other's way).
                                 // Measured: profiles/r03/midsize_split_groups.log (+3 ... +8 % for 24-111 evaluations at N >= 2048)
     int split_small = 1;        // option "split_small": smaller groups too, where it was measured to pay (same log): 13-23 evaluations

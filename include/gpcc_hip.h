@@ -122,7 +122,7 @@ int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms
  * "fit_speculate" / "fit_threads" (gpcc_grid_loglik on the small-N path: the kernel unpacks the optimiser's vectors itself;
  * latency-bound rounds evaluate all four candidate points of an iteration at once; large grids run as up to 4 slices on host
  * threads, 0 = by size -- none of the three changes a bit of the result).  "right_looking_max" now defaults to 12.
- * "split_min" / "split_max" / "split_nt_min" (24 / 160 / 12): a group of split_min ... split_max evaluations at N > 128 (split_nt_min - 1)
+ * "split_min" / "split_max" / "split_nt_min" (24 / 240 (round 3: 160) / 12): a group of split_min ... split_max evaluations at N > 128 (split_nt_min - 1)
  * runs as two halves on two streams (the update of one half hides the diagonal-step / panel-solve chain of the other); split_min = 0:
  * never.  "split_small" (1): also 13-23 evaluations up to N = 2048 (13-19 up to N = 3072) and 6-12 evaluations from N = 2945 on, where that was measured to pay.
  * Diagnostic options (A/B measurements; defaults are the measured best): "hybrid_occ" (384: only steps with fewer left-looking jobs
