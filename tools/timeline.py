@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Timeline of ONE batch under the default dispatch (run under rocprofv3 --kernel-trace; --parse <dir> [skip]): per kernel type the
+"""Timeline of the calls after the last idle gap (> 0.3 ms) under the default dispatch (run under rocprofv3 --kernel-trace;
+--parse <dir> [dump]; the run mode makes three back-to-back calls and prints each call's host-visible time): per kernel type the
 launch count, summed duration and mean grid, the wall span of the batch and the union of the kernels' intervals (how much of the wall
 at least one kernel was running).
     rocprofv3 --kernel-trace -d gpurun_out/tl -- python3 tools/timeline.py 2048 32 [key=value ...]
@@ -15,9 +16,12 @@ if len(sys.argv) > 2 and sys.argv[1] == "--parse":
         rows = con.execute("select name, grid_x, workgroup_x, start, end from %s order by start" % kt[0]).fetchall()
         rows = [r for r in rows if "gpcc" in r[0]]
         # the last batch = everything from the last gpcc_assemble_tiles launch(es) on: find the last gap > 200 us before an assemble
-        idx = [i for i, r in enumerate(rows) if "assemble" in r[0]]
-        nasm = 2 if (len(idx) >= 2 and rows[idx[-1]][3] - rows[idx[-2]][3] < 2e6) else 1   # (split groups assemble twice)
-        first = idx[-nasm]
+        # the last batch = everything after the last idle gap of more than 0.3 ms (the host's work between two calls)
+        first, emax = 0, rows[0][4]
+        for i in range(1, len(rows)):
+            if rows[i][3] - emax > 3e5:
+                first = i
+            emax = max(emax, rows[i][4])
         rows = rows[first:]
         t0, t1 = rows[0][3], max(r[4] for r in rows)
         if len(sys.argv) > 3 and sys.argv[3] == "dump":   # every launch of the batch: start, end (us from the first), grid
@@ -52,5 +56,8 @@ with gpcc_amd.Objective(t, y, s, "matern32") as obj:
     for kv in sys.argv[3:]:
         k, v = kv.split("=")
         obj.set_option(k, int(v))
+    import time
     for _ in range(3):
+        t0 = time.perf_counter()
         obj.loglik_batch(d, a, r)
+        print("host-visible time of the call: %.3f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
