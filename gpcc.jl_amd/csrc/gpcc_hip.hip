@@ -132,8 +132,9 @@ struct gpcc_handle_s {
                              // the same results.  OFF: the overlap works (profiles/r04/look_ahead_second_form_timeline.log) but the extra launch of
                              // latency-bound single-tile jobs costs what the hidden chain saves: +1 % for 13-20 evaluations at N = 4096, -2 ... -5 %
                              // for the split groups of 24-64 (profiles/r04/look_ahead_midsize_ab.log)
-    int fold_assembly = 1;   // option "fold_assembly": fused left-looking fp64 groups of the exponential kernels do not assemble the off-diagonal
-                             // tiles that lie inside one band pair; gpcc_update_solve evaluates them into its accumulators (GpccCtx::fold)
+    int fold_assembly = 1;   // option "fold_assembly": groups of more than fused_small_max evaluations do not assemble the off-diagonal tiles; the job
+                             // of the factorisation that reads a tile first (gpcc_update_solve / gpcc_panel_update) evaluates it into its
+                             // accumulators, bit for bit the assembled tile (GpccCtx::fold)
     int step_fused = 0;      // option "step_fused": ... as ONE launch per step (gpcc_step: the diagonal step of column k+1 inside the update
                              // launch of column k, on half a CU's LDS); 0 = the two launches of round 2
     int diag_blocks = 0;     // option "diag_blocks": the three-kernel path's diagonal step on the packed block image (gpcc_diag_factor2,
