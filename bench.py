@@ -59,7 +59,9 @@ def update_flops_per_eval(N, fused=True):
 
 
 def gpu_state(index=0):
-    """One sample of the GPU's shader clock (MHz) and socket power (W): sysfs first (no subprocess), rocm-smi as a fallback.
+    """One sample of the GPU's shader clock (MHz) and socket power (W): from sysfs only -- no child process is ever started (a sample that sysfs
+    cannot give stays None: this runs on a sampler thread during the timed region, and under a profiler preload a child's exec hop is
+    what the pool forbids).
     Box-to-box spread of the headline is +-2 %; with this in the line a 2 % move can be told from a clock / power difference."""
     import glob
     out = {"sclk_mhz": None, "power_w": None}
@@ -90,20 +92,6 @@ def gpu_state(index=0):
                         break
     except Exception:
         pass
-    if out["sclk_mhz"] is None or out["power_w"] is None:
-        try:
-            import subprocess
-            r = subprocess.run(["rocm-smi", "-d", str(index), "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=20)
-            d = json.loads(r.stdout)
-            card = next(iter(d.values()))
-            for k, v in card.items():
-                kl = k.lower()
-                if out["sclk_mhz"] is None and "sclk" in kl and "mhz" in str(v).lower():
-                    out["sclk_mhz"] = int("".join(ch for ch in str(v) if ch.isdigit()))
-                if out["power_w"] is None and "power" in kl and "(w)" in kl:
-                    out["power_w"] = float(v)
-        except Exception:
-            pass
     return out
 
 
@@ -410,7 +398,6 @@ def main():
         group = min(G, slots)
         fused = (not small) and obj.get_option("fused_solve") == 1 and group >= obj.get_option("fused_solve_min") \
             and group > obj.get_option("right_looking_max")
-        one_launch = fused and obj.get_option("step_fused") == 1     # gpcc_step: the diagonal step inside the update launch
         peak = FP64_MFMA_PEAK_TFLOPS if (args.precision == "fp64" or small) else FP32_MFMA_PEAK_TFLOPS
         timing_note = ("separate profiled pass after the timed region: HIP events around every launch on its own stream, "
                        "groups serialised on one stream (gpcc_profile_*); rocprofv3 --kernel-trace --stats of the same command: profiles/")
@@ -418,9 +405,6 @@ def main():
         if small:
             wide = G <= obj.get_option("small_wide_max") or N > 191
             names = {"small_eval": "gpcc_smallw_eval" if wide else "gpcc_small_eval"}
-        elif one_launch:
-            names = {"assemble": "gpcc_assemble_tiles", "panel_update": "gpcc_step",
-                     "refine": "gpcc_back_solve+gpcc_refine_partials+gpcc_refine_finish"}
         elif fused:
             names = {"assemble": "gpcc_assemble_tiles", "panel_update": "gpcc_update_solve", "diag_factor": "gpcc_syrk_diag",
                      "refine": "gpcc_back_solve+gpcc_refine_partials+gpcc_refine_finish"}
@@ -441,11 +425,7 @@ def main():
         else:
             launches, total_ms = prof["panel_update"]
             kname = names["panel_update"]
-            if one_launch:       # the whole factorisation: every tile's dgemm + dtrsm, the diagonal tiles' dsyrk (lower blocks) and potf2
-                nt_ = (N + TILE - 1) // TILE
-                flops_eval = update_flops_per_eval(N, True)[0] + sum(36 * 2.0 * 16 ** 3 * 8 * k for k in range(nt_)) + nt_ * 2.0 * TILE ** 3 / 3.0
-            else:
-                flops_eval, _ = update_flops_per_eval(N, fused)
+            flops_eval, _ = update_flops_per_eval(N, fused)
         if launches > 0 and total_ms > 0:
             avg_ms = total_ms / launches
             flops_per_launch = flops_eval * G / launches      # algorithmic flops / launch (average over steps k)
@@ -457,7 +437,7 @@ def main():
                         # the diagonal tiles run elsewhere): both accountings, so that neither has to be re-derived
                         "frac_n3_over_3": round(n3 * G / launches / (avg_ms * 1e-3) / 1e12 / peak, 4),
                         "frac_accounting": "frac: the flops THIS kernel performs (%s); frac_n3_over_3: N^3/3 per evaluation over the same launches"
-                                           % ("N^3/3 + N^2" if small else "whole factorisation" if one_launch else "dgemm + dtrsm of the tiles I > k" if fused else "dgemm tiles + dsyrk diagonal tile"),
+                                           % ("N^3/3 + N^2" if small else "dgemm + dtrsm of the tiles I > k" if fused else "dgemm tiles + dsyrk diagonal tile"),
                         "traffic": traffic, "traffic_source": tsrc, "launches": launches, "avg_launch_ms": round(avg_ms, 4),
                         "algorithmic_flops_per_launch": flops_per_launch, "timing": timing_note,
                         "end_to_end_tflops": round(end_to_end, 3), "end_to_end_frac": round(end_to_end / peak, 4),
@@ -470,7 +450,7 @@ def main():
                 # still write is the diagonal tiles (+ tile column 0 on the three-kernel path) and 4 N doubles of per-point factors
                 folded = (obj.get_option("fold_assembly") == 1 and nt > 1 and G > obj.get_option("fused_small_max")
                           and (args.kernel != "rbf" or (args.precision == "fp32" and obj.get_option("fp32_assemble") == 1)))
-                tiles_written = (nt + (0 if fused or one_launch else nt - 1)) if folded else nt * (nt + 1) / 2
+                tiles_written = (nt + (0 if fused else nt - 1)) if folded else nt * (nt + 1) / 2
                 abytes = (esz * TILE * TILE * tiles_written + (32.0 * N if folded else 0.0)) * G / max(an, 1)
                 roofline["assemble"] = {"bound": "hbm", "achieved": round(abytes / (ams / max(an, 1) * 1e-3) / 1e9, 1),
                                         "peak": 8000.0, "unit": "GB/s", "avg_launch_ms": round(ams / max(an, 1), 4),

@@ -22,6 +22,7 @@ BATCH_OBJECTIVE = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_long,
 
 SIGNATURES = {
     "gpcc_version": (ctypes.c_int, []),
+    "gpcc_build_info": (ctypes.c_char_p, []),
     "gpcc_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
     "gpcc_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, c_int_p, c_double_p, c_double_p,
                                    c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
@@ -65,6 +66,7 @@ SIGNATURES = {
     "gpcc_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "gpcc_profile_reset": (ctypes.c_int, [ctypes.c_void_p]),
     "gpcc_profile_get": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_long_p, c_double_p]),
+    "gpcc_chain_trace": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, ctypes.c_int]),
     "gpcc_selftest": (ctypes.c_int, [ctypes.c_int, c_double_p]),
 }
 

@@ -233,6 +233,13 @@ class Objective:
         self._chk(_capi.load().gpcc_multi_stats(self._h, _dp(comp), ctypes.byref(g), ctypes.byref(tot)))
         return comp, g.value, tot.value
 
+    def chain_trace(self, evaluation=0):
+        """Stamps of the last persistent few-evaluation launch (option "chain_trace" = 1): (nt, 4) microseconds (gpcc_chain_trace)."""
+        nt = self.get_option("Np") // 128
+        out = np.empty(4 * nt, dtype=np.float64)
+        self._chk(_capi.load().gpcc_chain_trace(self._h, int(evaluation), _dp(out), out.size))
+        return out.reshape(nt, 4)
+
     # -- the hot path ---------------------------------------------------------------------------
     def _params(self, delays, alpha, rho):
         rho = _d(np.atleast_1d(rho))
@@ -400,3 +407,8 @@ def selftest(device=0, rate=True):
     tf = ctypes.c_double(0.0)
     _capi.check(_capi.load().gpcc_selftest(int(device), ctypes.byref(tf) if rate else None))
     return tf.value
+
+
+def build_info():
+    """What the loaded library was built from: "src=<hash of its sources> defines=[...]" (gpcc_build_info)."""
+    return _capi.load().gpcc_build_info().decode()

@@ -1,21 +1,55 @@
-"""Builds csrc/libgpcc_hip.so (hipcc, gfx950 only).  Cross-compiles without a GPU."""
+"""Builds csrc/libgpcc_hip.so (hipcc, gfx950 only).  Cross-compiles without a GPU.
+
+What a library was built FROM travels with it: the SHA-256 of the sources and of the extra compiler defines is compiled into the
+library (`gpcc_build_info()`) and written beside it (`<library>.buildinfo`); the library is stale when that record does not match the
+tree.  Extra defines (GPCC_BUILD_DEFINES: the A/B switches of tools/) are refused for the default output path: the product library is
+always the plain build."""
+import hashlib
 import os
 import shutil
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.environ.get("GPCC_HIP_LIB") or os.path.join(CSRC, "libgpcc_hip.so")
-_SOURCES = ["gpcc_hip.hip", "gpcc_small_inst.hip", "gpcc_kernels.hip.h", "gpcc_small.hip.h", "gpcc_fit.h", "gpcc_transforms.h"]
+DEFAULT_LIB_PATH = os.path.join(CSRC, "libgpcc_hip.so")
+LIB_PATH = os.environ.get("GPCC_HIP_LIB") or DEFAULT_LIB_PATH
+_SOURCES = ["gpcc_hip.hip", "gpcc_small_inst.hip", "gpcc_kernels.hip.h", "gpcc_chain.hip.h", "gpcc_small.hip.h", "gpcc_fit.h", "gpcc_transforms.h"]
 _HEADER = os.path.join(os.path.dirname(_HERE), "include", "gpcc_hip.h")
+
+
+def _defines():
+    d = os.environ.get("GPCC_BUILD_DEFINES", "").split()
+    if d and os.path.realpath(LIB_PATH) == os.path.realpath(DEFAULT_LIB_PATH):
+        raise RuntimeError("GPCC_BUILD_DEFINES=%r with the default library path %s: A/B builds go to their own file (set GPCC_HIP_LIB); "
+                           "the product library is always the plain build" % (" ".join(d), DEFAULT_LIB_PATH))
+    return d
+
+
+def source_hash():
+    """SHA-256 (first 16 hex digits) of every source of the library and of the extra defines."""
+    h = hashlib.sha256()
+    for path in [os.path.join(CSRC, s) for s in _SOURCES] + [_HEADER]:
+        if os.path.exists(path):
+            h.update(os.path.basename(path).encode() + b"\0")
+            with open(path, "rb") as f:
+                h.update(f.read())
+    h.update(" ".join(os.environ.get("GPCC_BUILD_DEFINES", "").split()).encode())
+    return h.hexdigest()[:16]
+
+
+def build_info_string():
+    d = " ".join(os.environ.get("GPCC_BUILD_DEFINES", "").split())
+    return "src=%s defines=[%s]" % (source_hash(), d)
 
 
 def _stale():
     if not os.path.exists(LIB_PATH):
         return True
-    so_m = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in _SOURCES] + [_HEADER]
-    return any(os.path.exists(d) and os.path.getmtime(d) > so_m for d in deps)
+    try:
+        with open(LIB_PATH + ".buildinfo") as f:
+            return f.read().strip() != build_info_string()
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=False):
@@ -36,7 +70,9 @@ def build(force=False, verbose=False):
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
     flags = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed", "-Wno-inline-asm", "-c"]
-    flags += os.environ.get("GPCC_BUILD_DEFINES", "").split()     # A/B builds (tools/ab_exp.sh: -DGPCC_AB_POLY_EXP into GPCC_HIP_LIB)
+    flags += _defines()     # A/B builds only (tools/ab_*.sh: e.g. -DGPCC_AB_POLY_EXP into GPCC_HIP_LIB; refused for the default path)
+    info = build_info_string()
+    flags += ['-DGPCC_BUILD_INFO_STR="%s"' % info]
     objdir = tempfile.mkdtemp(prefix="gpcc_build_")
     jobs = [(os.path.join(objdir, "gpcc_hip.o"), [os.path.join(CSRC, "gpcc_hip.hip")])]
     for wide in (1, 0):
@@ -69,12 +105,14 @@ def build(force=False, verbose=False):
         print(report)
         raise RuntimeError("hipcc failed (%d command%s):\n%s" % (len(failed), "" if len(failed) == 1 else "s", report))
     os.replace(tmp, LIB_PATH)
+    with open(LIB_PATH + ".buildinfo", "w") as f:
+        f.write(info + "\n")
     return LIB_PATH
 
 
 def ensure_present(local_rank=0, timeout_s=900.0):
     """For launchers that start one process per GPU: local rank 0 (re)builds the library when it is missing OR older
-    than its sources (the same mtime check as build()), the other ranks wait until an up-to-date file is there --
+    than its sources (the same content-hash check as build()), the other ranks wait until an up-to-date file is there --
     so a benchmark never times a stale library after an edit of csrc/."""
     import time
     if local_rank == 0:

@@ -1,0 +1,851 @@
+// gpcc_chain.hip.h -- the FEW-EVALUATION path of libgpcc_hip.so (gfx950 / CDNA4 only): ONE persistent launch per group of at most
+// `chain_max` evaluations (default 12) at N >= 384 -- call site 1 of the boundary, a single objective(alpha, rho)
+// (/root/reference/src/gpccfixdelay_marginaliseb.jl:133-141, called one at a time by Optim's Nelder-Mead, :145-153, :209-211).
+//
+// Why: one evaluation's blocked Cholesky (cholesky(K), marginaliseb.jl:139) is a serial chain
+//     diag(k) -> solve of tile (k+1,k) -> update of tile (k+1,k+1) -> diag(k+1) -> ...
+// and as launches (gpcc_panel_trsm_rows + gpcc_small_step, 2 per step) every link waits for the previous one to END: 34 us diagonal
+// step + 8 us solve + 8 us update per step, 1.83 ms at N = 4096 with >= 80 % of the CUs idle.  Kernel time, not launch overhead -- so
+// moving the same links into one launch would buy nothing.  What this kernel changes is WHEN a link may start:
+//   * the diagonal step publishes inv(L_kk) ROW BLOCK BY ROW BLOCK (16 rows each, as its software pipeline completes them) -- a
+//     column solve consumes row block f the moment it exists, so when the diagonal step ends only the last of eight pieces is left;
+//   * the solve of tile (k+1,k) (four quarter-tile jobs on four CUs) publishes L(k+1,k) COLUMN BLOCK BY COLUMN BLOCK, and the workgroup
+//     that will run diag(k+1) folds each one into tile (k+1,k+1) as it arrives (held in registers: 36 lower 16x16 blocks);
+//   * two CHAIN workgroups per evaluation alternate: while A runs diag(k), B builds the image of tile (k+1,k+1); when A's last row
+//     block is out, B is ~3 hand-offs (a few us) from its first pivot.
+// Everything else -- the solves of the other tiles of column k and the right-looking trailing update -- is pulled as JOBS from an
+// in-order queue by all other CUs ("workers"), sequenced by per-tile counters in global memory instead of kernel boundaries.
+//
+// Hand-offs follow /opt/skills/guides (MI355X_MICROARCH.md, inter-workgroup visibility; cdna_hip_programming.md Guideline 16): every
+// byte another workgroup reads is stored `sc1` (write-through), every storing wave drains (`s_waitcnt vmcnt(0)`), the workgroup
+// meets at a barrier, ONE lane signals (an `sc1` flag store or an agent-scope atomic add); a consumer polls with relaxed `sc1` loads
+// from one lane, releases its workgroup through a barrier, and loads the bytes with `sc1` loads only -- register loads
+// (buffer_load_dwordx4 / global_load_dwordx2 ... sc1) and LDS-DMA (global_load_lds_dwordx4 ... sc1).  The LDS-DMA form is not in the
+// guide's table; tools/xcd_probe.hip measured it on the box (consumer L1-warm, uneven load, every word checked:
+// profiles/r05/xcd_probe_handoff_forms_and_hop_prices.log: 0 stale words of 157 M, the plain forms 31 %) -- measured, not an
+// architectural guarantee.  A hop costs 0.6 us (flag) to 1.6 us (flag + 16 KiB).
+//
+// No deadlock, whatever is resident: chain workgroups are the lowest block indices (dispatched first); a worker takes jobs in queue
+// order and a job only waits for jobs EARLIER in that order or for the chain, so the oldest unfinished job can always run.  Every
+// spin is bounded (GPCC_CHAIN_SPIN_LIMIT polls, seconds): on expiry the waiter sets the abort word, every other waiter sees it and
+// leaves, and the evaluation reports info = GPCC_INFO_TIMEOUT instead of hanging the GPU.
+//
+// Arithmetic: the same tile algorithm as the launch-per-step path (right-looking, 128 x 128 tiles, the 16-wide blocked diagonal
+// step with its explicit inverse, fused forward substitution), other summation orders inside a tile: results agree to ~1e-13.
+// A non-positive pivot does not stop anything (NaNs flow through, every flag is still published); the first one is reported as
+// `info`, LAPACK-style, like everywhere else.  fp64 handles only (nrhs = 1).
+#pragma once
+#include "gpcc_kernels.hip.h"
+
+#define GPCC_CHAIN_THREADS 512
+#define GPCC_CHAIN_LDS_BYTES (96 * 1024)   /* > 80 KiB on purpose: ONE workgroup per CU -- the pivot chain runs 2-3x slower beside MFMA waves */
+#define GPCC_CHAIN_MAX_EVALS 16
+#define GPCC_CHAIN_SPIN_LIMIT (1u << 22)
+#define GPCC_CHAIN_MAXRHS 4
+#define GPCC_XIMG_ELEMS (36 * 256)         /* the lower 36 blocks of inv(L_kk), 16 x 16 row-major each */
+#define GPCC_INFO_TIMEOUT (-9)
+#define GPCC_CHAIN_STEPVALS (2 + GPCC_CHAIN_MAXRHS * GPCC_CHAIN_MAXRHS)
+
+typedef unsigned gpcc_u4 __attribute__((ext_vector_type(4)));
+#ifndef GPCC_CHAIN_FN
+#define GPCC_CHAIN_FN __device__ __forceinline__
+#endif
+
+struct GpccChainArgs {
+    unsigned *words;             // zeroed before every launch: [0] abort word; [16 + k] job counter of step k; then per evaluation (ev_words each):
+                                 //   xrow[nt] | colflag[nt][8] | lcnt[ntiles] | ver[ntiles]
+    double *ximg;                // evaluations x nt x GPCC_XIMG_ELEMS: inv(L_kk) as published (block (f, ch) at gpcc_bi(f, ch), [row][col] row-major)
+    double *stepval;             // evaluations x nt x GPCC_CHAIN_STEPVALS: per diagonal step [sum log L_ii of the block, first bad pivot, W'W]
+    unsigned long long *trace;   // optional (NULL): evaluations x nt x 4 wall-clock stamps of the chain (tools/chain_trace.py)
+    int ev_words;                // words per evaluation
+    int qbase;                   // first per-evaluation word
+};
+
+// ---- agent-scope accesses (all hand-off traffic): relaxed atomics lower to global_load / global_store ... sc1
+__device__ __forceinline__ unsigned gpcc_flag_ld(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gpcc_flag_st(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned gpcc_flag_add(unsigned *p, unsigned v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double gpcc_ld_sc1(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void gpcc_st_sc1(double *p, double v)
+{
+    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// 16-byte sc1 accesses through a buffer descriptor built from a wave-uniform base (aux 16 = sc1); byte offsets per lane
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gpcc_rsrc(const void *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)gpcc_uniform_ptr(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ d2 gpcc_ld16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
+{
+    return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16));
+}
+__device__ __forceinline__ void gpcc_st16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, d2 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gpcc_u4, v), r, (int)byte_off, 0, 16);
+}
+// two consecutive 1 KiB LDS-DMA pieces, sc1 (gpcc_dma_piece2 with the cache policy of a hand-off)
+__device__ __forceinline__ void gpcc_dma_piece2_sc1(const void *gbase, unsigned voff, unsigned lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024 sc1"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(gbase)
+                 : "memory", "m0");
+}
+__device__ __forceinline__ void gpcc_dma_chunk_sc1(const double *gA, const double *gB, unsigned stage_addr, int wave, int lane)
+{
+    const int uw = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned voff = (unsigned)lane * 16u;
+    gpcc_dma_piece2_sc1(gpcc_uniform_ptr(gA + uw * 256), voff, stage_addr + uw * 2048);
+    gpcc_dma_piece2_sc1(gpcc_uniform_ptr(gB + uw * 256), voff, stage_addr + GPCC_CHUNK_BYTES + uw * 2048);
+}
+
+// ONE lane polls *p until it is >= want; false = the launch is being abandoned (somebody's spin expired, or this one did)
+__device__ __forceinline__ bool gpcc_wait_ge(const unsigned *p, unsigned want, unsigned *abortw, unsigned code)
+{
+    for (unsigned spins = 0;; ++spins) {
+        if (gpcc_flag_ld(p) >= want) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 31u) == 31u && gpcc_flag_ld(abortw) != 0u) return false;
+        if (spins > GPCC_CHAIN_SPIN_LIMIT) {
+            gpcc_flag_st(abortw, code);
+            return false;
+        }
+    }
+}
+__device__ __forceinline__ int gpcc_tile_idx(int I, int J) { return I * (I + 1) / 2 + J; }
+// the flag words of evaluation m
+struct GpccChainFlags {
+    unsigned *abortw, *xrow, *colflag, *lcnt, *ver;
+};
+__device__ __forceinline__ GpccChainFlags gpcc_chain_flags(const GpccChainArgs &a, int nt, int m)
+{
+    GpccChainFlags f;
+    unsigned *ev = a.words + a.qbase + (long)m * a.ev_words;
+    const int ntiles = nt * (nt + 1) / 2;
+    f.abortw = a.words;
+    f.xrow = ev;
+    f.colflag = ev + nt;
+    f.lcnt = ev + 9 * nt;
+    f.ver = ev + 9 * nt + ntiles;
+    return f;
+}
+
+// ------------------------------------------------------------------------------------------
+// The diagonal step of the chain: gpcc_diag_body's algorithm (blocked dpotf2 by 16, explicit inverse, W_k = inv(L_kk) Z_k, sum log
+// L_ii, W'W, first bad pivot) on a PACKED image -- the LOWER TRIANGLE only, 36 blocks of 16 x 16 doubles (72 KiB), the inverse built
+// IN PLACE (LAPACK dtrtri's trick, block-wise):
+//   * block (i, j), j <= i, at gpcc_bi(i, j); element (r, c) of a block at gpcc_be(r, c): physical row r ^ bit2(r), the sixteen
+//     8-byte slots of a row XOR-ed with 2 (row >> 1) -- no padding, and both MFMA fragment patterns (A operand: lane (lr, q) reads
+//     [lr][q + 4 s]; B operand / accumulator: [q + 4 s][lr]) are bank-conflict-free;
+//   * a diagonal block holds D_b until wave 0 has factored it and inv(L_D)^T afterwards (L_D itself is read by nobody: the panel
+//     multiplies by inv(L_D), sum log L_ii comes from the register factorisation);
+//   * row i of inv(L) -- X[i][j] = -inv(D_i) sum_{m=j}^{i-1} L[i][m] X[m][j] -- reads ALL of L's row i and nothing else of row i is
+//     read later, so after one barrier X[i][j] overwrites L[i][j].
+// Eight waves: wave 0 runs the register factorisations (lanes 0-15 own the rows of D, lanes 16-31 the columns of inv(L_D), ONE
+// right-looking instruction stream for both, software-pipelined), six workers the MFMA tasks, wave 4 (wave 0's SIMD mate) stays out
+// of its way -- and PUBLISHES: row block i of inv(L) is final one barrier after it was built, and wave 4 copies it to global memory
+// (`ximg`, row-major 16 x 16 blocks: a lane of a consumer finds its MFMA operand as 32 contiguous bytes) during the next block
+// step, then sets xrow = i + 1.  The last row block goes out on all eight waves together with W_k and the step's scalars; xrow = 9
+// says all of it is there.  (History: this image was built in round 4 for a half-CU diagonal kernel, measured beside
+// MFMA-saturating waves, and rejected there -- LOG.md; alone on a CU it is what lets TWO workgroups per evaluation alternate.)
+// ------------------------------------------------------------------------------------------
+#define GPCC_OPAQUE_LANE(a, b) asm volatile("" : "+v"(a), "+v"(b))
+
+// block (i, j) of the image -> ximg, row-major; one wave.  Diagonal blocks hold inv(L_D)^T in the image and leave untransposed.
+__device__ __forceinline__ void gpcc_chain_publish_block(const double *sB, __amdgpu_buffer_rsrc_t xr, int i, int j, int lane)
+{
+    const int r = lane >> 2, c0 = 4 * (lane & 3);
+    double v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (i == j) ? sB[gpcc_bi(i, i) + gpcc_be(c0 + e, r)] : sB[gpcc_bi(i, j) + gpcc_be(r, c0 + e)];
+    const unsigned off = (unsigned)(gpcc_bi(i, j) + r * 16 + c0) * 8u;
+    d2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+    gpcc_st16_sc1(xr, off, lo);
+    gpcc_st16_sc1(xr, off + 16u, hi);
+}
+
+// PRE: the image (36 blocks at smem) holds the updated lower triangle of tile (k,k), behind a barrier.  Returns false if abandoned.
+GPCC_CHAIN_FN void gpcc_chain_diag(const GpccCtx &c, const GpccGroup &g, const GpccChainArgs &a, const GpccChainFlags &fl, const int k,
+                                   const int m, double *smem, const int tid)
+{
+    typedef GpccPrec<double> PD;
+    double *sB = smem;                                   // 36 blocks
+    double *sz = sB + GPCC_XIMG_ELEMS;                   // nrhs x 128: Z_k, later W_k
+    double *sr = sz + GPCC_CHAIN_MAXRHS * GPCC_TILE;     // [0, 80): wave 0's column scratch; [96, 112): per-block statistics
+    int *sbad = (int *)(sr + GPCC_TILE);
+
+    const int lane = tid & 63, lr = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NWK = 6, NT = GPCC_CHAIN_THREADS;
+    const int wk = (wave == 0 || wave == 4) ? -1 : (wave < 4 ? wave - 1 : wave - 2);
+    const int slot = g.slot0 + m, nrhs = c.nrhs;
+    const bool last = (k == c.nt - 1);
+    double *xk = a.ximg + ((long)m * c.nt + k) * GPCC_XIMG_ELEMS;
+    const __amdgpu_buffer_rsrc_t xr = gpcc_rsrc(xk, GPCC_XIMG_ELEMS * 8);
+
+    for (int e = tid; e < nrhs * GPCC_TILE; e += NT)
+        sz[e] = gpcc_ld_sc1(c.z + ((long)slot * nrhs + e / GPCC_TILE) * c.Np + k * GPCC_TILE + (e % GPCC_TILE));
+    if (tid == 0) *sbad = 0;
+    __syncthreads();
+    for (int jb = 0; jb <= 8; ++jb) {
+        const int r0 = jb * 16;
+        int lrv = lr, qv = q;   // opaque per-phase copies: keeps the compiler from hoisting every lane-dependent address of all nine rounds out of the loop
+        GPCC_OPAQUE_LANE(lrv, qv);
+        d4 xo[2];            // rows of inv(L) built in this round: written after the barrier (in place of L's row)
+        int xj[2] = {-1, -1};
+        if (wave == 4 && jb >= 2) {   // row block jb - 2 of inv(L) is final: out it goes (nothing of it is written any more)
+            for (int j = 0; j <= jb - 2; ++j) gpcc_chain_publish_block(sB, xr, jb - 2, j, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) gpcc_flag_st(&fl.xrow[k], (unsigned)(jb - 1));
+        }
+        if (wave == 0) {
+            if (jb > 0 && jb < 8) {   // C(jb-1) for the block the factorisation below needs: D_jb -= P_jb P_jb^T
+                d4 x;
+                double pa[4], pb[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = sB[gpcc_bi(jb, jb) + gpcc_be(qv + 4 * r, lrv)];
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    pb[s2] = sB[gpcc_bi(jb, jb - 1) + gpcc_be(lrv, qv + 4 * s2)];
+                    pa[s2] = -pb[s2];
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) x = PD::mfma(pa[s2], pb[s2], x);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sB[gpcc_bi(jb, jb) + gpcc_be(qv + 4 * r, lrv)] = x[r];
+            }
+            if (jb < 8) {
+                // ---- (A) 16x16 potf2 + inverse in registers: lanes 0-15 own the rows of D, lanes 16-31 the columns of inv(L_D); ONE
+                // right-looking instruction stream for both: once column j of L is final, v[j] <- v[j] / sqrt(d_j) is L[l][j] on an L lane
+                // and X[j][l] on an X lane, and the same v[cc] -= v[j] L[cc][j] updates the trailing row and the running sums
+                const bool xl = qv != 0;
+                double v[16];
+                double *blk = sB + gpcc_bi(jb, jb);
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc) v[cc] = xl ? ((cc == lrv) ? 1.0 : 0.0) : blk[gpcc_be(lrv, cc)];
+                int bad = 0;
+                double py = 1.0;   // prod of the mantissas of 1/sqrt(d_j) ...
+                int pe = 0;        // ... and the sum of their exponents: no overflow whatever the scale of K
+                // software-pipelined: the broadcast column of pivot j is fetched (cn) and applied to columns >= j+2 during the reciprocal
+                // square root of pivot j+1 -- only column j+1 (through v_readlane) is on the pivot-to-pivot chain
+                double cn[16];
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc) cn[cc] = 0.0;
+                double d = gpcc_bcast(v[0], 0), vp = 0.0;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (!(d > 0.0) && bad == 0) bad = j + 1;
+                    const double y = gpcc_rsqrt(d);
+                    if (j >= 1) {   // the rest of pivot j-1's rank-1 update (column j had its share through the readlane below)
+#pragma unroll
+                        for (int cc = j + 1; cc < 16; ++cc) {
+                            v[cc] = __builtin_fma(-vp, cn[cc], v[cc]);
+                            asm volatile("" : "+v"(v[cc]));   // applied NOW (left alone the compiler sinks the updates to their readers
+                                                              // and keeps every broadcast column alive: > 256 VGPRs)
+                        }
+                    }
+                    py *= __builtin_amdgcn_frexp_mant(y);
+                    pe += __builtin_amdgcn_frexp_exp(y);
+                    v[j] *= y;
+                    if (j < 15) {
+                        sr[qv == 0 ? lrv : 16 + lane] = v[j];
+                        const double lnx = gpcc_bcast(v[j], j + 1);
+                        v[j + 1] = __builtin_fma(-v[j], lnx, v[j + 1]);
+                        d = gpcc_bcast(v[j + 1], j + 1);
+                        vp = v[j];
+#pragma unroll
+                        for (int cc = j + 2; cc < 16; ++cc) cn[cc] = sr[cc];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (lane < 32) {
+                    if (xl) {   // column lrv of X = inv(L_D) as row lrv of the block: the block now holds inv(L_D)^T
+#pragma unroll
+                        for (int cc = 0; cc < 16; ++cc) blk[gpcc_be(lrv, cc)] = v[cc];
+                    }
+                    if (lane == 0 && bad && *sbad == 0) *sbad = r0 + bad;
+                    if (lane == 0) {
+                        sr[96 + jb] = py;
+                        sr[104 + jb] = (double)pe;
+                    }
+                }
+            }
+        } else if (wk >= 0 && jb > 0) {
+            const int jp = jb - 1;
+            // ---- (C) rest of the trailing update of column block jp
+            const int nb = 7 - jp, ntri = nb * (nb + 1) / 2;
+            for (int t0 = 1 + wk; t0 < ntri; t0 += 2 * NWK) {
+                int rfv[2], cfv[2];
+                bool on[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int tt = t0 + NWK * u;
+                    on[u] = tt < ntri;
+                    const int te = on[u] ? tt : t0;
+                    const int rr = (te >= 1) + (te >= 3) + (te >= 6) + (te >= 10) + (te >= 15) + (te >= 21);
+                    rfv[u] = jp + 1 + rr;
+                    cfv[u] = jp + 1 + te - rr * (rr + 1) / 2;
+                }
+                d4 x[2];
+                double pa[2][4], pb[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[u][r] = sB[gpcc_bi(rfv[u], cfv[u]) + gpcc_be(qv + 4 * r, lrv)];
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) {
+                        pa[u][s2] = -sB[gpcc_bi(rfv[u], jp) + gpcc_be(lrv, qv + 4 * s2)];
+                        pb[u][s2] = sB[gpcc_bi(cfv[u], jp) + gpcc_be(lrv, qv + 4 * s2)];
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    x[0] = PD::mfma(pa[0][s2], pb[0][s2], x[0]);
+                    x[1] = PD::mfma(pa[1][s2], pb[1][s2], x[1]);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (on[u]) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sB[gpcc_bi(rfv[u], cfv[u]) + gpcc_be(qv + 4 * r, lrv)] = x[u][r];
+                    }
+            }
+        }
+        GPCC_OPAQUE_LANE(lrv, qv);
+        if (jb > 0) {
+            // ---- (X) row i = jb-1 of inv(L) and (W) rows i of W_k, one task per worker (the last row: all eight waves)
+            const int i = jb - 1;
+            bool dow = false;
+            int j0 = -1, j1 = -1;
+            if (jb == 8) {
+                dow = wave == 0;
+                j0 = wave - 1;
+            } else if (wk >= 0) {
+                dow = wk == 0;
+                j0 = wk - 1;
+                j1 = (wk == NWK - 1) ? NWK - 1 : -1;
+            }
+            if (dow) {
+                const int zrow = (lrv < nrhs) ? lrv : 0;
+                d4 S, S1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double zv = sz[zrow * GPCC_TILE + i * 16 + qv + 4 * r];
+                    S[r] = (lrv < nrhs) ? -zv : 0.0;
+                }
+                for (int mm = 0; mm < i; ++mm) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) {
+                        const double av = sB[gpcc_bi(i, mm) + gpcc_be(lrv, qv + 4 * s2)];      // L[i][mm]
+                        const double wv = sz[zrow * GPCC_TILE + mm * 16 + qv + 4 * s2];
+                        const double bv = (lrv < nrhs) ? wv : 0.0;
+                        if (s2 & 1) S1 = PD::mfma(av, bv, S1);
+                        else S = PD::mfma(av, bv, S);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[r] += S1[r];
+                d4 Y = {0.0, 0.0, 0.0, 0.0}, Y1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double dv = -sB[gpcc_bi(i, i) + gpcc_be(qv + 4 * r, lrv)];           // inv(D_i)[lrv][qv + 4 r]
+                    if (r & 1) Y1 = PD::mfma(dv, S[r], Y1);
+                    else Y = PD::mfma(dv, S[r], Y);
+                }
+                if (lrv < nrhs) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sz[lrv * GPCC_TILE + i * 16 + qv + 4 * r] = Y[r] + Y1[r];
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int j = n ? j1 : j0;
+                if (j < 0 || j >= i) continue;
+                d4 S = {0.0, 0.0, 0.0, 0.0}, S1 = {0.0, 0.0, 0.0, 0.0};
+                for (int mm = j; mm < i; ++mm) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) {
+                        const double av = sB[gpcc_bi(i, mm) + gpcc_be(lrv, qv + 4 * s2)];                     // L[i][mm]
+                        const double bv = (mm == j) ? sB[gpcc_bi(j, j) + gpcc_be(lrv, qv + 4 * s2)]           // X[j][j][k][c]
+                                                    : sB[gpcc_bi(mm, j) + gpcc_be(qv + 4 * s2, lrv)];         // X[mm][j][k][c]
+                        if (s2 & 1) S1 = PD::mfma(av, bv, S1);
+                        else S = PD::mfma(av, bv, S);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[r] += S1[r];
+                d4 Y = {0.0, 0.0, 0.0, 0.0}, Y1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double dv = -sB[gpcc_bi(i, i) + gpcc_be(qv + 4 * r, lrv)];
+                    if (r & 1) Y1 = PD::mfma(dv, S[r], Y1);
+                    else Y = PD::mfma(dv, S[r], Y);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xo[n][r] = Y[r] + Y1[r];
+                xj[n] = j;
+            }
+        }
+        __syncthreads();   // every reader of L's row jb-1 is done
+        GPCC_OPAQUE_LANE(lrv, qv);
+        if (jb > 0) {
+            const int i = jb - 1;
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                if (xj[n] >= 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sB[gpcc_bi(i, xj[n]) + gpcc_be(qv + 4 * r, lrv)] = xo[n][r];   // X[i][j], untransposed
+                }
+        }
+        if (jb == 8) break;
+        GPCC_OPAQUE_LANE(lrv, qv);
+        // ---- (B) panel of column block jb: P = A[rf, jb] inv(D_jb)^T for the row fragments below, in place
+        for (int rf = jb + 1 + wave; rf < 8; rf += NT / 64) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                av[s2] = sB[gpcc_bi(rf, jb) + gpcc_be(lrv, qv + 4 * s2)];
+                bv[s2] = sB[gpcc_bi(jb, jb) + gpcc_be(qv + 4 * s2, lrv)];   // B[k][c] = inv(D)[c][k]
+            }
+            d4 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) x = PD::mfma(av[s2], bv[s2], x);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sB[gpcc_bi(rf, jb) + gpcc_be(qv + 4 * r, lrv)] = x[r];
+        }
+        __syncthreads();
+    }
+    __syncthreads();   // row block 7 of inv(L) is in the image, sz holds W_k
+    // ---- the end of the step goes out together: row block 7 of inv(L) (one block per wave), W_k, the step's scalars -- then ONE flag
+    // value says "all of step k is there"
+    gpcc_chain_publish_block(sB, xr, 7, wave, lane);
+    for (int e = tid; e < nrhs * GPCC_TILE; e += NT)
+        gpcc_st_sc1(c.w + ((long)slot * nrhs + e / GPCC_TILE) * c.Np + k * GPCC_TILE + (e % GPCC_TILE), sz[e]);
+    double *sv = a.stepval + ((long)m * c.nt + k) * GPCC_CHAIN_STEPVALS;
+    for (int e = wave; e < nrhs * nrhs; e += NT / 64) {   // this step's W'W: one wave per entry, fixed reduction tree
+        const int ga = e / nrhs, gb = e % nrhs;
+        double pr = sz[ga * GPCC_TILE + lane] * sz[gb * GPCC_TILE + lane] + sz[ga * GPCC_TILE + 64 + lane] * sz[gb * GPCC_TILE + 64 + lane];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) pr += __shfl_xor(pr, o);
+        if (lane == 0) gpcc_st_sc1(sv + 2 + e, pr);
+    }
+    if (wave == 3) {
+        double pr = 0.0;   // sum log L_jj per 16-block
+        if (lane < 8) pr = -(log(sr[96 + lane]) + sr[104 + lane] * 0.69314718055994530942);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) pr += __shfl_xor(pr, o);
+        if (lane == 0) {
+            gpcc_st_sc1(sv, pr);
+            gpcc_st_sc1(sv + 1, (double)*sbad);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains ...
+    __syncthreads();
+    if (tid == 0) gpcc_flag_st(&fl.xrow[k], 9u);        // ... ONE lane signals
+    if (last && tid == 0) {
+        // loglik = -(N log 2pi + logdet K)/2 - (Y-bbar)' K^-1 (Y-bbar)/2  (Distributions.logpdf, marginaliseb.jl:139): the steps' scalars in
+        // step order, the same running sums the launch-per-step path keeps (steps of the OTHER chain workgroup were published before its
+        // xrow = 9, which this workgroup has waited for, transitively, long ago)
+        double ld = 0.0, *G = sr;   // (the Gram matrix in LDS: gpcc_loglik_from_gram indexes it dynamically)
+        for (int e = 0; e < nrhs * nrhs; ++e) G[e] = 0.0;
+        int bad = c.info[slot];   // (argument errors, set by the assembly before the launch)
+        for (int kk = 0; kk < c.nt; ++kk) {
+            const double *s2 = a.stepval + ((long)m * c.nt + kk) * GPCC_CHAIN_STEPVALS;
+            ld = gpcc_ld_sc1(s2) + ld;
+            const int b = (int)gpcc_ld_sc1(s2 + 1);
+            if (bad == 0 && b != 0) bad = kk * GPCC_TILE + b;
+            for (int e = 0; e < nrhs * nrhs; ++e) G[e] = gpcc_ld_sc1(s2 + 2 + e) + G[e];
+        }
+        c.logdet[slot] = ld;
+        c.info[slot] = bad;
+        int bad2 = bad;
+        const double llv = gpcc_loglik_from_gram(c, G, nrhs, ld, bad2);
+        g.out_loglik[g.first + m] = bad2 ? __builtin_nan("") : llv;
+        g.out_info[g.first + m] = bad2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The image of tile (k,k) for the chain: lower triangle of T(k,k) (every update of columns < k-1 applied by the workers) minus
+// L(k,k-1) L(k,k-1)^T, the column blocks of L(k,k-1) folded in AS THE FOUR QUARTER SOLVES PUBLISH THEM (colflag).  36 blocks in the
+// registers of eight waves, dealt 5/5/5/5/4/4/4/4 (gpcc_syrk_lower_wave's split); a column block is 16 KiB, loaded by all threads with
+// sc1 register loads into one LDS stage.  Returns false if abandoned.
+// ------------------------------------------------------------------------------------------
+template <int RA, int CA, int NA, int RB, int CB, int NB>
+GPCC_CHAIN_FN bool gpcc_chain_syrk_wave(const double *Tt, const double *Lt, const unsigned *colflag, unsigned *abortw, double *smem, int *ctl,
+                                                     int tid, int lane)
+{
+    typedef GpccPrec<double> P;
+    const int lr = lane & 15, q = lane >> 4, sw = gpcc_sw(lr);
+    d4 acc[NA + NB];
+#pragma unroll
+    for (int i = 0; i < NA + NB; ++i) {
+        const int R = (i < NA) ? RA : RB, C = (i < NA) ? CA + i : CB + (i - NA);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] = -gpcc_ld_sc1(Tt + gpcc_elem_off<double>(16 * R + P::crow(q, r), 16 * C + lr));
+    }
+    const __amdgpu_buffer_rsrc_t lres = gpcc_rsrc(Lt, GPCC_TILE_ELEMS * 8);
+    const double *p0 = smem + lr * 16 + (((2 * q) ^ sw) * 2);
+    const double *p1 = smem + lr * 16 + (((2 * q + 1) ^ sw) * 2);
+    for (int ch = 0; ch < 8; ++ch) {
+        if (tid == 0) ctl[0] = gpcc_wait_ge(&colflag[ch], 4u, abortw, 0x100u + ch) ? 1 : 0;
+        __syncthreads();   // (also: every wave has finished the previous chunk's reads of the stage)
+        if (!ctl[0]) return false;
+        {
+            const d2 v0 = gpcc_ld16_sc1(lres, (unsigned)(ch * GPCC_CHUNK_BYTES + tid * 16));
+            const d2 v1 = gpcc_ld16_sc1(lres, (unsigned)(ch * GPCC_CHUNK_BYTES + (tid + 512) * 16));
+            *(d2 *)(smem + tid * 2) = v0;
+            *(d2 *)(smem + (tid + 512) * 2) = v1;
+        }
+        __syncthreads();
+        d2 aA[2], aB[2];
+        aA[0] = *(const d2 *)(p0 + RA * 16 * 16);
+        aA[1] = *(const d2 *)(p1 + RA * 16 * 16);
+        if (NB > 0) {
+            aB[0] = *(const d2 *)(p0 + RB * 16 * 16);
+            aB[1] = *(const d2 *)(p1 + RB * 16 * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < NA + NB; ++i) {
+            const int C = (i < NA) ? CA + i : CB + (i - NA);
+            d2 b[2];
+            b[0] = *(const d2 *)(p0 + C * 16 * 16);
+            b[1] = *(const d2 *)(p1 + C * 16 * 16);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[i] = P::mfma((i < NA) ? aA[s / 2][s % 2] : aB[s / 2][s % 2], b[s / 2][s % 2], acc[i]);
+        }
+    }
+    __syncthreads();   // the stage is dead: the image takes its place
+#pragma unroll
+    for (int i = 0; i < NA + NB; ++i) {
+        const int R = (i < NA) ? RA : RB, C = (i < NA) ? CA + i : CB + (i - NA);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) smem[gpcc_bi(R, C) + gpcc_be(P::crow(q, r), lr)] = -acc[i][r];
+    }
+    return true;
+}
+
+// one chain workgroup: role r of evaluation m runs the diagonal steps k = r, r + 2, ...
+__device__ __forceinline__ void gpcc_chain_role(const GpccCtx &c, const GpccGroup &g, const GpccChainArgs &a, const int m, const int role, double *smem, int *ctl)
+{
+    const int tid0 = threadIdx.x;
+    const int slot = g.slot0 + m;
+    const GpccChainFlags fl = gpcc_chain_flags(a, c.nt, m);
+    double *tiles = (double *)c.tiles + (long)slot * c.slot_stride;
+    if (role == ((c.nt - 1) & 1) && tid0 == 0) {   // what the caller sees if the launch is abandoned (the last step overwrites it)
+        g.out_loglik[g.first + m] = __builtin_nan("");
+        g.out_info[g.first + m] = GPCC_INFO_TIMEOUT;
+    }
+    for (int k = role; k < c.nt; k += 2) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));   // per-step opaque copy: keeps the compiler from hoisting every lane-dependent address of a step out of this loop (spills)
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        unsigned long long *tr = a.trace ? a.trace + ((long)m * c.nt + k) * 4 : nullptr;
+        if (tr && tid == 0) tr[0] = wall_clock64();
+        const double *Tt = tiles + gpcc_tile_off(k, k);
+        if (k == 0) {   // tile (0,0) as assembled (before the launch: plain loads): its lower 36 blocks -> image
+            for (int p0 = tid; p0 < GPCC_TILE_ELEMS / 2; p0 += GPCC_CHAIN_THREADS) {
+                const int e = p0 * 2;
+                const int ch = e / (GPCC_TILE * 16), rem = e % (GPCC_TILE * 16), r = rem / 16, ks = rem % 16;
+                const int col0 = ch * 16 + ((ks / 2) ^ gpcc_sw(r)) * 2;
+                if ((col0 >> 4) <= (r >> 4)) {
+                    const d2 v = *(const d2 *)(Tt + e);
+                    smem[gpcc_bi(r >> 4, col0 >> 4) + gpcc_be(r & 15, col0 & 15)] = v[0];
+                    smem[gpcc_bi(r >> 4, col0 >> 4) + gpcc_be(r & 15, (col0 & 15) + 1)] = v[1];
+                }
+            }
+        } else {
+            if (tid == 0) ctl[0] = gpcc_wait_ge(&fl.ver[gpcc_tile_idx(k, k)], (unsigned)(k - 1), fl.abortw, 0x200u) ? 1 : 0;
+            __syncthreads();
+            if (!ctl[0]) return;
+            const double *Lt = tiles + gpcc_tile_off(k, k - 1);
+            const unsigned *cf = fl.colflag + 8 * (k - 1);
+            bool ok;
+            switch (wave) {
+            case 0: ok = gpcc_chain_syrk_wave<7, 0, 5, 0, 0, 0>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane); break;
+            case 1: ok = gpcc_chain_syrk_wave<6, 0, 5, 0, 0, 0>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane); break;
+            case 2: ok = gpcc_chain_syrk_wave<5, 0, 5, 0, 0, 0>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane); break;
+            case 3: ok = gpcc_chain_syrk_wave<4, 0, 5, 0, 0, 0>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane); break;
+            case 4: ok = gpcc_chain_syrk_wave<7, 5, 3, 0, 0, 1>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane); break;
+            case 5: ok = gpcc_chain_syrk_wave<6, 5, 2, 1, 0, 2>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane); break;
+            case 6: ok = gpcc_chain_syrk_wave<5, 5, 1, 2, 0, 3>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane); break;
+            default: ok = gpcc_chain_syrk_wave<3, 0, 4, 0, 0, 0>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane); break;
+            }
+            if (!ok) return;
+        }
+        if (tr && tid == 0) tr[1] = wall_clock64();
+        gpcc_chain_diag(c, g, a, fl, k, m, smem, tid);   // (begins with a barrier behind its own loads: the image is complete for every wave)
+        if (tr && tid == 0) tr[2] = wall_clock64();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Worker job TRSMQ(I, k, qr): rows 32 qr .. 32 qr + 31 of L(I,k) = T(I,k) inv(L_kk)^T, column block f as soon as row block f of
+// inv(L_kk) is published (xrow[k] >= f + 1), fused with the forward substitution z_I -= L(I,k) w_k at the end (xrow[k] = 9).
+// Wave (rh, kq): rows 16 rh .. of the quarter, K chunks kq and kq + 4 (the A operand -- the wave's rows of T(I,k) -- in registers);
+// the four K partials of a block are summed through LDS in a fixed order by 256 threads that own (row, two columns) and write the
+// result in the tile's own byte layout with 16-byte sc1 stores.  For the tile below the diagonal (I = k + 1) every column block is
+// signalled separately (colflag[k][f]): the chain workgroup that builds tile (k+1,k+1) consumes them as they come.
+// ------------------------------------------------------------------------------------------
+GPCC_CHAIN_FN bool gpcc_chain_trsmq(const GpccCtx &c, const GpccChainArgs &a, const GpccChainFlags &fl, const int m, const int slot, const int k,
+                                    const int I, const int qr, double *smem, int *ctl, const int tid)
+{
+    typedef GpccPrec<double> P;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, q = lane >> 4, sw = gpcc_sw(lr);
+    const int rh = wave & 1, kq = wave >> 1;
+    const bool chain_tile = (I == k + 1);
+    double *tiles = (double *)c.tiles + (long)slot * c.slot_stride;
+    double *Tt = tiles + gpcc_tile_off(I, k);
+    const __amdgpu_buffer_rsrc_t tres = gpcc_rsrc(Tt, GPCC_TILE_ELEMS * 8);
+    const __amdgpu_buffer_rsrc_t xres = gpcc_rsrc(a.ximg + ((long)m * c.nt + k) * GPCC_XIMG_ELEMS, GPCC_XIMG_ELEMS * 8);
+    if (tid == 0) ctl[0] = gpcc_wait_ge(&fl.ver[gpcc_tile_idx(I, k)], (unsigned)k, fl.abortw, 0x300u) ? 1 : 0;
+    __syncthreads();
+    if (!ctl[0]) return false;
+    // A operand: T(I,k)[32 qr + 16 rh + lr][16 ch + 4 q .. 4 q + 3] for this wave's chunks ch = kq, kq + 4
+    d2 av[2][2];
+    {
+        const int row = 32 * qr + 16 * rh + lr;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int ch = kq + 4 * c2;
+            av[c2][0] = gpcc_ld16_sc1(tres, (unsigned)((ch * 2048 + row * 16 + (((2 * q) ^ sw) * 2)) * 8));
+            av[c2][1] = gpcc_ld16_sc1(tres, (unsigned)((ch * 2048 + row * 16 + (((2 * q + 1) ^ sw) * 2)) * 8));
+        }
+    }
+    // reducer threads (waves 0-3): (rh2, row, sp) = 16-byte slot sp (columns 2 sp, 2 sp + 1) of row 16 rh2 + row of the quarter
+    const int rh2 = tid >> 7, rrow = (tid >> 3) & 15, sp = tid & 7;
+    double lv[8][2];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {   // (unrolled: lv stays in registers)
+        if (tid == GPCC_CHAIN_THREADS - 64) ctl[0] = gpcc_wait_ge(&fl.xrow[k], (unsigned)(f + 1), fl.abortw, 0x310u + f) ? 1 : 0;   // (wave 7: not a reducer)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the reducers' stores of column block f - 1 have drained ...)
+        __syncthreads();
+        if (!ctl[0]) return false;
+        if (chain_tile && f > 0 && tid == 0) gpcc_flag_add(&fl.colflag[8 * k + f - 1], 1u);   // (... and ONE lane signals it)
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int ch = kq + 4 * c2;
+            if (ch <= f) {   // (wave-uniform)
+                const unsigned off = (unsigned)((gpcc_bi(f, ch) + lr * 16 + 4 * q) * 8);
+                const d2 b0 = gpcc_ld16_sc1(xres, off), b1 = gpcc_ld16_sc1(xres, off + 16u);
+                acc = P::mfma(av[c2][0][0], b0[0], acc);
+                acc = P::mfma(av[c2][0][1], b0[1], acc);
+                acc = P::mfma(av[c2][1][0], b1[0], acc);
+                acc = P::mfma(av[c2][1][1], b1[1], acc);
+            }
+        }
+        double *part = smem + (f & 1) * 2048 + wave * 256;   // [wave][row][col] of this column block's partials
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[P::crow(q, r) * 16 + lr] = acc[r];
+        __syncthreads();
+        if (tid < 256) {
+            const double *pp = smem + (f & 1) * 2048 + rh2 * 256 + rrow * 16 + 2 * sp;
+            d2 s = *(const d2 *)pp;                       // kq = 0
+            s += *(const d2 *)(pp + 2 * 256);            // kq = 1 (wave = 2 kq + rh)
+            s += *(const d2 *)(pp + 4 * 256);
+            s += *(const d2 *)(pp + 6 * 256);
+            lv[f][0] = s[0];
+            lv[f][1] = s[1];
+            const int row = 32 * qr + 16 * rh2 + rrow;
+            gpcc_st16_sc1(tres, (unsigned)((f * 2048 + row * 16 + ((sp ^ gpcc_sw(row)) * 2)) * 8), s);
+        }
+    }
+    // forward substitution of logpdf's whitening: z_I[row] -= sum_c L(I,k)[row][c] w_k[c]
+    if (tid == GPCC_CHAIN_THREADS - 64) ctl[0] = gpcc_wait_ge(&fl.xrow[k], 9u, fl.abortw, 0x320u) ? 1 : 0;
+    __syncthreads();
+    if (!ctl[0]) return false;
+    if (tid < 256) {
+        const double *wp = c.w + (long)slot * c.nrhs * c.Np + k * GPCC_TILE;
+        double pr = 0.0;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            pr = fma(lv[f][0], gpcc_ld_sc1(wp + 16 * f + 2 * sp), pr);
+            pr = fma(lv[f][1], gpcc_ld_sc1(wp + 16 * f + 2 * sp + 1), pr);
+        }
+        pr += __shfl_xor(pr, 1);
+        pr += __shfl_xor(pr, 2);
+        pr += __shfl_xor(pr, 4);
+        if (sp == 0) {
+            double *zp = c.z + (long)slot * c.nrhs * c.Np + I * GPCC_TILE + 32 * qr + 16 * rh2 + rrow;
+            gpcc_st_sc1(zp, gpcc_ld_sc1(zp) - pr);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        if (chain_tile) gpcc_flag_add(&fl.colflag[8 * k + 7], 1u);
+        gpcc_flag_add(&fl.lcnt[gpcc_tile_idx(I, k)], 1u);
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// Worker job UPD(I, J, k): the right-looking trailing update T(I,J) -= L(I,k) L(J,k)^T of one tile (gpcc_small_step's tile job:
+// 8 waves x (32 x 64), operands by LDS-DMA into a 2-deep ring -- here with sc1 --, the result out through LDS in the tile's own
+// byte layout as 16-byte sc1 stores), once both column tiles are complete (lcnt = 4 quarters) and the tile has received column
+// k - 1 (ver = k).
+// ------------------------------------------------------------------------------------------
+GPCC_CHAIN_FN bool gpcc_chain_upd(const GpccCtx &c, const GpccChainFlags &fl, const int slot, const int k, const int I, const int J, double *smem,
+                                  int *ctl, const int tid)
+{
+    typedef GpccPrec<double> P;
+    constexpr int CH = 2048;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, q = lane >> 4, sw = gpcc_sw(lr);
+    if (tid == 0) {
+        bool ok = gpcc_wait_ge(&fl.lcnt[gpcc_tile_idx(I, k)], 4u, fl.abortw, 0x400u);
+        ok = ok && gpcc_wait_ge(&fl.lcnt[gpcc_tile_idx(J, k)], 4u, fl.abortw, 0x401u);
+        ok = ok && gpcc_wait_ge(&fl.ver[gpcc_tile_idx(I, J)], (unsigned)k, fl.abortw, 0x402u);
+        ctl[0] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!ctl[0]) return false;
+    double *tiles = (double *)c.tiles + (long)slot * c.slot_stride;
+    const double *gA = (const double *)gpcc_uniform_ptr(tiles + gpcc_tile_off(I, k)), *gB = (const double *)gpcc_uniform_ptr(tiles + gpcc_tile_off(J, k));
+    double *Tt = tiles + gpcc_tile_off(I, J);
+    const unsigned smem_addr = gpcc_lds_addr(smem);
+    gpcc_dma_chunk_sc1(gA, gB, smem_addr, wave, lane);
+    d4 acc[2][4];
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[fm][fn][r] = -gpcc_ld_sc1(Tt + gpcc_elem_off<double>(wr * 32 + fm * 16 + P::crow(q, r), wc * 64 + fn * 16 + lr));
+    const double *pa0 = smem + (wr * 32 + lr) * 16 + (((2 * q) ^ sw) * 2);
+    const double *pa1 = smem + (wr * 32 + lr) * 16 + (((2 * q + 1) ^ sw) * 2);
+    const double *pb0 = smem + CH + (wc * 64 + lr) * 16 + (((2 * q) ^ sw) * 2);
+    const double *pb1 = smem + CH + (wc * 64 + lr) * 16 + (((2 * q + 1) ^ sw) * 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 2
+    for (int ch = 0; ch < 8; ++ch) {   // one tile of K: the chunks of L(I,k) and L(J,k)
+        const int st = ch & 1;
+        if (ch + 1 < 8) gpcc_dma_chunk_sc1(gA + (long)(ch + 1) * CH, gB + (long)(ch + 1) * CH, smem_addr + (st ^ 1) * 2 * GPCC_CHUNK_BYTES, wave, lane);
+        const int so = st * 2 * CH;
+        d2 a2[2][2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            a2[f][0] = *(const d2 *)(pa0 + so + f * 16 * 16);
+            a2[f][1] = *(const d2 *)(pa1 + so + f * 16 * 16);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            d2 b[2][2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                b[f][0] = *(const d2 *)(pb0 + so + (2 * h + f) * 16 * 16);
+                b[f][1] = *(const d2 *)(pb1 + so + (2 * h + f) * 16 * 16);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) acc[fm][2 * h + f] = P::mfma(a2[fm][s / 2][s % 2], b[f][s / 2][s % 2], acc[fm][2 * h + f]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // out through LDS in the tile's own byte layout, rows 64 hv .. 64 hv + 63 at a time (64 KiB), then linear 16-byte sc1 stores
+    const __amdgpu_buffer_rsrc_t tres = gpcc_rsrc(Tt, GPCC_TILE_ELEMS * 8);
+#pragma unroll
+    for (int hv = 0; hv < 2; ++hv) {
+        if ((wr >> 1) == hv) {
+#pragma unroll
+            for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+                for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rl = (wr & 1) * 32 + fm * 16 + P::crow(q, r), ch = 4 * wc + fn;
+                        smem[ch * 1024 + rl * 16 + (((lr / 2) ^ gpcc_sw(rl)) * 2) + (lr % 2)] = -acc[fm][fn][r];
+                    }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch)   // 512 sixteen-byte pieces per chunk and half: one per thread
+            gpcc_st16_sc1(tres, (unsigned)((ch * CH + hv * 1024 + tid * 2) * 8), *(const d2 *)(smem + ch * 1024 + tid * 2));
+        if (hv == 0) __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) gpcc_flag_st(&fl.ver[gpcc_tile_idx(I, J)], (unsigned)(k + 1));
+    return true;
+}
+
+// per-evaluation jobs of step k (n = nt - k - 1 tile rows below the diagonal tile): 4 n quarter solves, then n(n+1)/2 - 1 tile
+// updates (tile (k+1,k+1) belongs to the chain)
+__host__ __device__ __forceinline__ int gpcc_chain_jobs(int n) { return n <= 0 ? 0 : 4 * n + n * (n + 1) / 2 - 1; }
+
+// grid: the chain block range (16 per 8 evaluations: blocks b and b + 8 -- one XCD, as dispatched -- are the two roles of an
+// evaluation) + workers; block 512; LDS GPCC_CHAIN_LDS_BYTES.
+__global__ __launch_bounds__(GPCC_CHAIN_THREADS, 2) void gpcc_chain_kernel(GpccCtx c, GpccGroup g, GpccChainArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double *smem = (double *)smem_raw;
+    int *ctl = (int *)(smem_raw + GPCC_CHAIN_LDS_BYTES - 64);
+    const int b = blockIdx.x, tid0 = threadIdx.x;
+    const int ncb = 16 * ((g.cnt + 7) / 8);
+    if (b < ncb) {
+        const int m = (b >> 4) * 8 + (b & 7), role = (b >> 3) & 1;
+        if (m < g.cnt) {
+            gpcc_chain_role(c, g, a, m, role, smem, ctl);
+            return;
+        }
+    }
+    // ---- worker: jobs in queue order, step by step
+    int ks = 0;
+    for (;;) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));   // (per-job opaque copy, as in gpcc_chain_role)
+        if (tid == 0) {
+            int j = -1;
+            while (ks < c.nt - 1) {
+                const int nj = g.cnt * gpcc_chain_jobs(c.nt - ks - 1);
+                const int t = (int)gpcc_flag_add(&a.words[16 + ks], 1u);
+                if (t < nj) {
+                    j = t;
+                    break;
+                }
+                ++ks;
+            }
+            ctl[1] = j;
+            ctl[2] = ks;
+        }
+        __syncthreads();
+        const int j = ctl[1];
+        ks = ctl[2];
+        __syncthreads();   // (ctl is rewritten by the job's own waits)
+        if (j < 0) return;
+        const int m = j % g.cnt, jj = j / g.cnt, k = ks, n = c.nt - k - 1, slot = g.slot0 + m;
+        const GpccChainFlags fl = gpcc_chain_flags(a, c.nt, m);
+        bool ok;
+        if (jj < 4 * n) {
+            ok = gpcc_chain_trsmq(c, a, fl, m, slot, k, k + 1 + jj / 4, jj % 4, smem, ctl, tid);
+        } else {
+            const int u = jj - 4 * n;
+            int ra, rb;   // tile (k + 1 + ra, k + 1 + rb), rb <= ra, (0,0) excluded: column k + 1 first (the next step's solves wait for it)
+            if (u < n - 1) {
+                ra = u + 1;
+                rb = 0;
+            } else {
+                const int v = u - (n - 1);   // pairs 1 <= rb <= ra <= n - 1, row-major
+                int t = (int)((sqrtf(8.0f * v + 1.0f) - 1.0f) * 0.5f);
+                while (t * (t + 1) / 2 > v) --t;
+                while ((t + 1) * (t + 2) / 2 <= v) ++t;
+                ra = 1 + t;
+                rb = 1 + (v - t * (t + 1) / 2);
+            }
+            ok = gpcc_chain_upd(c, fl, slot, k, k + 1 + ra, k + 1 + rb, smem, ctl, tid);
+        }
+        if (!ok) return;
+        __syncthreads();
+    }
+}

@@ -2,6 +2,7 @@
 // kernels of gpcc_kernels.hip.h.  No CPU fallback: every compute entry needs a HIP device.
 #include "gpcc_kernels.hip.h"
 #include "gpcc_small.hip.h"
+#include "gpcc_chain.hip.h"
 #include "gpcc_fit.h"
 
 #include "../../include/gpcc_hip.h"
@@ -120,33 +121,28 @@ struct gpcc_handle_s {
                              // profiles/r03/two_streams_ab.log); a batch of one group is unaffected
     int slots_per_stream = 256, right_looking_max = GPCC_RIGHT_LOOKING_MAX;
     int fused_small_max = 12;  // groups of at most this many evaluations run gpcc_small_step (update + next diagonal step in one launch)
+    int chain_max = 12;        // option "chain_max": ... or, fp64 handles, as ONE persistent launch (gpcc_chain.hip.h); 0 = never
+    std::atomic<long> chain_count{0};   // evaluations that took the persistent launch so far ("chain_count")
+    int chain_trace = 0;       // option "chain_trace": the chain workgroups stamp their phases (gpcc_chain_trace; tools/chain_trace.py)
+    unsigned *d_chain_words = nullptr;             // per workspace stream: the launch's flag words (zeroed before every launch)
+    double *d_ximg = nullptr, *d_stepval = nullptr;   // ... the published inverses of the diagonal blocks, the steps' scalars
+    unsigned long long *d_chain_trace = nullptr;
+    long chain_region_words = 0;                   // words per stream region
+    int chain_ev_words = 0, chain_qbase = 0, chain_streams = 0, n_cus = 0;
     int shared_prefix = 1;   // 0 off, 1 auto (host-pointer API detects it), 2 the caller asserts it
-    int update_t = 0;        // diagnostic option "update_t": the three-kernel path with gpcc_update_solve<T, false> as its update (A/B of the transposed main loop)
     int fused_solve_min = 112;   // ... from this group size on (below it the diagonal tile's serial K-loop on ONE CU per evaluation costs
                                  // more than the fused solve saves: measured crossover 96-128 evaluations at N = 1024 and N = 4096)
     int fused_solve_min_split = 64;   // option "fused_solve_min_split": ... for the two halves of a split group (split_min): 128-160 evaluations at
                                  // N = 4096 +1.5 ... 2 %, at N = 2048 +4 ... 6 % (profiles/r04/fused_solve_min_sweep_after_fold.log)
     int fused_solve = 1;     // option "fused_solve": left-looking groups run gpcc_syrk_diag + gpcc_update_solve (2 launches per step)
-    int look_ahead = 0;      // option "look_ahead": right-looking steps of the three-kernel path update column k + 1 first, then run its diagonal
-                             // step and panel solve beside the rest of the trailing update (which goes to a low-priority helper stream); bitwise
-                             // the same results.  OFF: the overlap works (profiles/r04/look_ahead_second_form_timeline.log) but the extra launch of
-                             // latency-bound single-tile jobs costs what the hidden chain saves: +1 % for 13-20 evaluations at N = 4096, -2 ... -5 %
-                             // for the split groups of 24-64 (profiles/r04/look_ahead_midsize_ab.log)
     int fold_assembly = 1;   // option "fold_assembly": groups of more than fused_small_max evaluations do not assemble the off-diagonal tiles; the job
                              // of the factorisation that reads a tile first (gpcc_update_solve / gpcc_panel_update) evaluates it into its
                              // accumulators, bit for bit the assembled tile (GpccCtx::fold)
-    int step_fused = 0;      // option "step_fused": ... as ONE launch per step (gpcc_step: the diagonal step of column k+1 inside the update
-                             // launch of column k, on half a CU's LDS); 0 = the two launches of round 2
-    int diag_blocks = 0;     // option "diag_blocks": the three-kernel path's diagonal step on the packed block image (gpcc_diag_factor2,
-                             // 80 KiB of LDS: two workgroups per CU, or one beside an update workgroup); 0 = gpcc_diag_factor (158.7 KiB)
     int hybrid_tail = 1;     // option "hybrid_tail": left-looking groups of the three-kernel path finish RIGHT-looking once their
                              // trailing matrices fit the Infinity Cache and the left-looking steps would leave CUs idle
     int hybrid_mall_mb = 400;   // option "hybrid_mall_mb": budget for the trailing matrices of a group (256 MiB Infinity Cache; measured
                                 // best at 400: profiles/r03/midsize_tail_budget_sweep.log)
     int hybrid_occ = 384;       // option "hybrid_occ": ... and only steps with fewer left-looking jobs than this become right-looking
-    int trsm_rows_jobs = 0;     // option "trsm_rows_jobs": three-kernel steps with at most this many panel-solve jobs use gpcc_panel_trsm_rows (quarter-
-                                // tile jobs on four times as many CUs).  Measured at 128: +1 ... +2.7 % for 13-64 evaluations at N = 2048, +0.4 % at
-                                // N = 4096 -- left OFF: the bits of an evaluation would then depend on the size of its group
     int split_min = 24;         // option "split_min": a group of at least this many evaluations (0 = never) runs as TWO halves on two
                                 // streams, so that the update of one half hides the diagonal-step / panel-solve chain of the other ...
     int split_max = 240;        // option "split_max": ... up to this many (a full group of 256 has no idle chain left to hide: -1.3 % when split).  Round 3: 160
@@ -184,8 +180,6 @@ struct gpcc_handle_s {
     hipEvent_t ev_done[GPCC_MAX_STREAMS] = {};
     hipStream_t str2[GPCC_MAX_STREAMS] = {};      // second half of a split group (option "split_min")
     hipEvent_t ev_fork[GPCC_MAX_STREAMS] = {}, ev_join[GPCC_MAX_STREAMS] = {};
-    hipStream_t str_la[GPCC_MAX_STREAMS][2] = {};  // look-ahead helpers of str[] ([i][0]) and str2[] ([i][1]): the chain diagonal step -> panel solve
-    hipEvent_t ev_la[GPCC_MAX_STREAMS][2][2] = {}; // ... and their fork / join events (option "look_ahead")
     hipEvent_t ev_start = nullptr;
     hipStream_t main_stream = nullptr;
     // staging for the host-pointer API
@@ -263,6 +257,11 @@ static int fail(gpcc_handle_t h, int code, const char *fmt, ...)
     } while (0)
 
 extern "C" int gpcc_version(void) { return GPCC_VERSION_NUMBER; }
+
+#ifndef GPCC_BUILD_INFO_STR
+#define GPCC_BUILD_INFO_STR "src=unknown defines=[?]"   /* (a build that did not go through gpcc.jl_amd/build.py) */
+#endif
+extern "C" const char *gpcc_build_info(void) { return GPCC_BUILD_INFO_STR; }
 
 extern "C" const char *gpcc_last_error(gpcc_handle_t h) { return h ? h->err.c_str() : g_err.c_str(); }
 
@@ -357,7 +356,8 @@ extern "C" int gpcc_create(gpcc_handle_t *out, int L, const int *Nl, const doubl
         // memory -- not of what happens to be free: the group size selects the factorisation path, so the same handle must dispatch the
         // same way on every run whatever else occupies the GPU (if the memory is not there when the workspace is allocated, the
         // workspace shrinks and says so: ensure_workspace)
-        double per_slot = ((double)h->nt * (h->nt + 1) / 2 + (precision ? h->nt : 2)) * GPCC_TILE_ELEMS * (precision ? 4.0 : 8.0) + 16.0 * h->Np * (L + 1);
+        double per_slot = ((double)h->nt * (h->nt + 1) / 2 + (precision ? h->nt : 1)) * GPCC_TILE_ELEMS * (precision ? 4.0 : 8.0) + 16.0 * h->Np * (L + 1) +
+                          32.0 * h->Np + 4.0 * h->nt + 32.0;   // (+ the separable factors u, A, B, a of every point, the tile-row flags, the scale)
         if (precision)   // fp32 mode: diag(K) as assembled, the refinement's per-tile partial sums, the pivot-ratio statistics
             per_slot += 8.0 * h->Np + 8.0 * GPCC_MAXRHS * GPCC_MAXRHS * ((double)h->nt * (h->nt + 1) / 2) + 16.0;
         size_t free_b = 0, total_b = 0;
@@ -435,6 +435,8 @@ static void free_workspace(gpcc_handle_t h)
     hipFree(h->d_tiles); hipFree(h->d_linv); hipFree(h->d_z); hipFree(h->d_w);
     hipFree(h->d_logdet); hipFree(h->d_quad); hipFree(h->d_info); hipFree(h->d_kdiag); hipFree(h->d_cond); hipFree(h->d_gpart);
     hipFree(h->d_sep); hipFree(h->d_seps); hipFree(h->d_sepflag);
+    hipFree(h->d_chain_words); hipFree(h->d_ximg); hipFree(h->d_stepval); hipFree(h->d_chain_trace);
+    h->d_chain_words = nullptr; h->d_ximg = h->d_stepval = nullptr; h->d_chain_trace = nullptr; h->chain_streams = 0;
     h->d_tiles = h->d_linv = h->d_z = h->d_w = h->d_logdet = h->d_quad = h->d_kdiag = h->d_cond = h->d_gpart = nullptr;
     h->d_sep = h->d_seps = nullptr;
     h->d_info = h->d_sepflag = nullptr;
@@ -444,11 +446,6 @@ static void free_workspace(gpcc_handle_t h)
         if (h->str2[s]) { hipStreamDestroy(h->str2[s]); h->str2[s] = nullptr; }
         if (h->ev_fork[s]) { hipEventDestroy(h->ev_fork[s]); h->ev_fork[s] = nullptr; }
         if (h->ev_join[s]) { hipEventDestroy(h->ev_join[s]); h->ev_join[s] = nullptr; }
-        for (int j = 0; j < 2; ++j) {
-            if (h->str_la[s][j]) { hipStreamDestroy(h->str_la[s][j]); h->str_la[s][j] = nullptr; }
-            for (int e = 0; e < 2; ++e)
-                if (h->ev_la[s][j][e]) { hipEventDestroy(h->ev_la[s][j][e]); h->ev_la[s][j][e] = nullptr; }
-        }
     }
     h->ws_ready = false;
 }
@@ -493,21 +490,19 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->right_looking_max = (int)v;
     } else if (!strcmp(key, "fused_small_max")) {
         h->fused_small_max = (int)v;
-    } else if (!strcmp(key, "update_t")) {
-        h->update_t = (int)v;
+    } else if (!strcmp(key, "chain_max")) {
+        if (v < 0 || v > GPCC_CHAIN_MAX_EVALS) return fail(h, GPCC_ERR_ARGUMENT, "chain_max must be in [0,%d]", GPCC_CHAIN_MAX_EVALS);
+        h->chain_max = (int)v;
+    } else if (!strcmp(key, "chain_trace")) {
+        h->chain_trace = v != 0;
+        if (h->chain_trace && !h->d_chain_trace) h->chain_streams = 0;   // (the buffers are rebuilt with a trace area on the next launch)
     } else if (!strcmp(key, "fused_solve")) {
         h->fused_solve = v != 0;
     } else if (!strcmp(key, "fused_solve_min_split")) {
         if (v < 1) return fail(h, GPCC_ERR_ARGUMENT, "fused_solve_min_split must be >= 1");
         h->fused_solve_min_split = (int)v;
-    } else if (!strcmp(key, "look_ahead")) {
-        h->look_ahead = v != 0;
     } else if (!strcmp(key, "fold_assembly")) {
         h->fold_assembly = v != 0;
-    } else if (!strcmp(key, "step_fused")) {
-        h->step_fused = v != 0;
-    } else if (!strcmp(key, "diag_blocks")) {
-        h->diag_blocks = v != 0;
     } else if (!strcmp(key, "fused_solve_min")) {
         h->fused_solve_min = (int)v;
         // (the halves of a split group follow: a caller who moves the threshold away from its default range -- to pin a path -- pins
@@ -521,8 +516,6 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->hybrid_tail = v != 0;
     } else if (!strcmp(key, "hybrid_occ")) {
         h->hybrid_occ = (int)v;
-    } else if (!strcmp(key, "trsm_rows_jobs")) {
-        h->trsm_rows_jobs = (int)v;
     } else if (!strcmp(key, "split_max")) {
         h->split_max = (int)v;
     } else if (!strcmp(key, "split_nt_min")) {
@@ -570,27 +563,27 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "workspace_slots")) return h->ws_ready ? h->ws_slots : h->slots_per_stream;  //  memory was short at allocation)
     if (!strcmp(key, "right_looking_max")) return h->right_looking_max;
     if (!strcmp(key, "fused_small_max")) return h->fused_small_max;
+    if (!strcmp(key, "chain_max")) return h->chain_max;
+    if (!strcmp(key, "chain_count")) return h->chain_count;
+    if (!strcmp(key, "chain_trace")) return h->chain_trace;
     if (!strcmp(key, "shared_prefix")) return h->shared_prefix;
     if (!strcmp(key, "share_tiles")) return h->share_tiles;
     if (!strcmp(key, "N")) return h->N;
     if (!strcmp(key, "Np")) return h->Np;
     if (!strcmp(key, "bytes_per_slot"))
-        return (long)(((long)h->nt * (h->nt + 1) / 2 + (h->precision ? h->nt : 2)) * GPCC_TILE_ELEMS) * (h->precision ? 4 : 8) + 16L * h->Np * h->nrhs +
+        return (long)(((long)h->nt * (h->nt + 1) / 2 + (h->precision ? h->nt : 1)) * GPCC_TILE_ELEMS) * (h->precision ? 4 : 8) + 16L * h->Np * h->nrhs +
+               32L * h->Np + 4L * h->nt + 32L +
                (h->precision ? 8L * h->Np + 8L * GPCC_MAXRHS * GPCC_MAXRHS * ((long)h->nt * (h->nt + 1) / 2) + 16L : 0L);
     if (!strcmp(key, "precision")) return h->precision;
     if (!strcmp(key, "fused_solve")) return h->fused_solve;
     if (!strcmp(key, "fused_solve_min")) return h->fused_solve_min;
     if (!strcmp(key, "fused_solve_min_split")) return h->fused_solve_min_split;
-    if (!strcmp(key, "look_ahead")) return h->look_ahead;
     if (!strcmp(key, "fold_assembly")) return h->fold_assembly;
-    if (!strcmp(key, "step_fused")) return h->step_fused;
-    if (!strcmp(key, "diag_blocks")) return h->diag_blocks;
     if (!strcmp(key, "small_n")) return h->small_n;
     if (!strcmp(key, "hybrid_tail")) return h->hybrid_tail;
     if (!strcmp(key, "hybrid_mall_mb")) return h->hybrid_mall_mb;
     if (!strcmp(key, "split_min")) return h->split_min;
     if (!strcmp(key, "split_max")) return h->split_max;
-    if (!strcmp(key, "trsm_rows_jobs")) return h->trsm_rows_jobs;
     if (!strcmp(key, "split_nt_min")) return h->split_nt_min;
     if (!strcmp(key, "split_small")) return h->split_small;
     if (!strcmp(key, "fit_speculate")) return h->fit_speculate;
@@ -642,16 +635,10 @@ static int set_kernel_attributes(gpcc_handle_t h)
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_update_solve<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_update_solve<double, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_update_solve<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_update_solve<double, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_update_solve<float, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<double, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<double, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<float, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<float, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_step<double>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_step<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_UPSOLVE_LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_diag_factor2<double>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_DB_LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_diag_factor2<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_DB_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<double, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_update<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
@@ -659,7 +646,44 @@ static int set_kernel_attributes(gpcc_handle_t h)
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_trsm<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_trsm_rows<double>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_TRSM_ROWS_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_trsm_rows<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_TRSM_ROWS_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_CHAIN_LDS_BYTES));
     return 0;
+}
+
+// the buffers of the persistent few-evaluation launch (gpcc_chain.hip.h), one region per workspace stream; built on first use
+static int ensure_chain(gpcc_handle_t h)
+{
+    if (h->d_chain_words && h->chain_streams == h->ws_streams) return 0;
+    HIPCHK(h, hipDeviceSynchronize());
+    hipFree(h->d_chain_words); hipFree(h->d_ximg); hipFree(h->d_stepval); hipFree(h->d_chain_trace);
+    h->d_chain_words = nullptr; h->d_ximg = h->d_stepval = nullptr; h->d_chain_trace = nullptr; h->chain_streams = 0;
+    const long ntiles = (long)h->nt * (h->nt + 1) / 2;
+    h->chain_qbase = 16 + (h->nt + 15) / 16 * 16;
+    h->chain_ev_words = (int)((9L * h->nt + 2 * ntiles + 3) / 4 * 4);
+    h->chain_region_words = ((long)h->chain_qbase + (long)GPCC_CHAIN_MAX_EVALS * h->chain_ev_words + 63) / 64 * 64;
+    const long S = h->ws_streams, E = GPCC_CHAIN_MAX_EVALS;
+    HIPCHK(h, hipMalloc(&h->d_chain_words, sizeof(unsigned) * h->chain_region_words * S));
+    HIPCHK(h, hipMalloc(&h->d_ximg, sizeof(double) * S * E * h->nt * GPCC_XIMG_ELEMS));
+    HIPCHK(h, hipMalloc(&h->d_stepval, sizeof(double) * S * E * h->nt * GPCC_CHAIN_STEPVALS));
+    if (h->chain_trace) {
+        HIPCHK(h, hipMalloc(&h->d_chain_trace, sizeof(unsigned long long) * S * E * h->nt * 4));
+        HIPCHK(h, hipMemset(h->d_chain_trace, 0, sizeof(unsigned long long) * S * E * h->nt * 4));
+    }
+    if (!h->n_cus) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || n <= 0) n = 256;
+        h->n_cus = n;
+    }
+    h->chain_streams = h->ws_streams;
+    return 0;
+}
+
+// a group of a few evaluations (one objective(alpha, rho)) on an fp64 handle's own workspace: the persistent launch
+static bool takes_chain(gpcc_handle_t h, const GpccCtx &c, int cnt)
+{
+    return h->chain_max > 0 && cnt <= h->chain_max && cnt <= GPCC_CHAIN_MAX_EVALS && cnt <= h->right_looking_max && c.nt > 1 && c.nt_fact == c.nt &&
+           !c.share_p && !c.store_l && c.nrhs == 1 && !c.woodbury && h->precision == GPCC_PRECISION_FP64 && c.tiles == (void *)h->d_tiles &&
+           h->d_chain_words != nullptr && h->chain_streams == h->ws_streams;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -677,7 +701,7 @@ static int ensure_workspace(gpcc_handle_t h)
         free_workspace(h);
         const long slots = (long)run_streams * run_slots;
         hipError_t e = hipMalloc(&h->d_tiles, esz * h->slot_stride * slots);
-        if (e == hipSuccess) e = hipMalloc(&h->d_linv, esz * GPCC_TILE_ELEMS * slots * (h->precision == GPCC_PRECISION_FP32 ? h->nt : 2));
+        if (e == hipSuccess) e = hipMalloc(&h->d_linv, esz * GPCC_TILE_ELEMS * slots * (h->precision == GPCC_PRECISION_FP32 ? h->nt : 1));
         if (e == hipSuccess) e = hipMalloc(&h->d_z, sizeof(double) * h->Np * h->nrhs * slots);
         if (e == hipSuccess) e = hipMalloc(&h->d_w, sizeof(double) * h->Np * h->nrhs * slots);
         if (e == hipSuccess) e = hipMalloc(&h->d_logdet, sizeof(double) * slots);
@@ -705,15 +729,6 @@ static int ensure_workspace(gpcc_handle_t h)
         HIPCHK(h, hipStreamCreateWithFlags(&h->str2[s], hipStreamNonBlocking));
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork[s], hipEventDisableTiming));
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[s], hipEventDisableTiming));
-        for (int j = 0; j < 2; ++j) {
-            {   // the helper runs the bulk of a trailing update; the chain on the main stream is the critical path and goes first
-                int prio_lo = 0, prio_hi = 0;
-                (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-                HIPCHK(h, hipStreamCreateWithPriority(&h->str_la[s][j], hipStreamNonBlocking, prio_lo));
-            }
-            HIPCHK(h, hipEventCreateWithFlags(&h->ev_la[s][j][0], hipEventDisableTiming));
-            HIPCHK(h, hipEventCreateWithFlags(&h->ev_la[s][j][1], hipEventDisableTiming));
-        }
     }
     { int rc_ = set_kernel_attributes(h); if (rc_) return rc_; }
     h->ws_streams = run_streams;
@@ -736,7 +751,7 @@ static GpccCtx make_ctx(gpcc_handle_t h)
     c.tiles = h->d_tiles; c.linv = h->d_linv; c.z = h->d_z; c.w = h->d_w;
     c.logdet = h->d_logdet; c.gram = h->d_quad; c.info = h->d_info;
     c.kdiag = h->d_kdiag; c.cond = h->d_cond; c.gpart = h->d_gpart;
-    c.linv_keep = (h->precision == GPCC_PRECISION_FP32) ? 1 : 2;
+    c.linv_keep = (h->precision == GPCC_PRECISION_FP32) ? 1 : 0;
     c.t = h->d_t; c.sig2 = h->d_sig2; c.resid = h->d_resid; c.band = h->d_band; c.yv = h->d_yv;
     c.tmid = h->tmid;
     c.sep = h->d_sep; c.seps = h->d_seps; c.sepflag = h->d_sepflag; c.fold = 0; c.fold_mixed = 0;
@@ -803,11 +818,9 @@ static int enqueue_group(gpcc_handle_t h, const GpccCtx &c_in, const GpccGroup &
     if (factor && !ext && h->fold_assembly && c.sep && c.nt > 1 && !c.share_p && c.nt_fact == c.nt && !c.store_l) {
         const bool right = g.cnt <= h->right_looking_max;
         if (takes_fused_solve(h, c, g.cnt, concurrent)) c.fold = 1;
-        else if (!(right && g.cnt <= h->fused_small_max) && !h->update_t) c.fold = 2;   // (not the gpcc_small_step path of a few evaluations)
-        // tile rows that straddle two bands or hold padding: the MIXED instantiations (a handle without such rows keeps the leaner ones;
-        // gpcc_step has no MIXED form)
-        c.fold_mixed = (c.fold && (h->mixed_rows || c.kernel_id == 1) && !(c.fold == 1 && h->step_fused)) ? 1 : 0;
-        if (c.kernel_id == 1 && !c.fold_mixed && !(single && c.asm32)) c.fold = 0;   // (rbf with gpcc_step: nothing to fold in fp64)
+        else if (!(right && (g.cnt <= h->fused_small_max || takes_chain(h, c, g.cnt)))) c.fold = 2;   // (not the few-evaluation paths)
+        // tile rows that straddle two bands or hold padding: the MIXED instantiations (a handle without such rows keeps the leaner ones)
+        c.fold_mixed = (c.fold && (h->mixed_rows || c.kernel_id == 1)) ? 1 : 0;
     }
     if (c.fold) {
         ProfScope p(h, GPCC_PROF_ASSEMBLE, s);
@@ -848,18 +861,6 @@ static int enqueue_group(gpcc_handle_t h, const GpccCtx &c_in, const GpccGroup &
     return 0;
 }
 
-// the look-ahead helper of a workspace stream (each of str[] / str2[] has its own stream and pair of events); false for any other stream
-static bool find_helper(gpcc_handle_t h, hipStream_t s, hipStream_t *sla, hipEvent_t *ev_a, hipEvent_t *ev_b)
-{
-    for (int i = 0; i < GPCC_MAX_STREAMS; ++i)
-        for (int j = 0; j < 2; ++j)
-            if (s && s == (j ? h->str2[i] : h->str[i]) && h->str_la[i][j]) {
-                *sla = h->str_la[i][j]; *ev_a = h->ev_la[i][j][0]; *ev_b = h->ev_la[i][j][1];
-                return true;
-            }
-    return false;
-}
-
 template <typename T>
 static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g_in, hipStream_t s, int concurrent)
 {
@@ -871,6 +872,30 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
     // small groups (the single objective(alpha, rho) call): right-looking, many short jobs per step
     const bool right = (g.cnt <= h->right_looking_max) && (c.nt_fact == c.nt) && !c.share_p;
     const int p = c.share_p;   // shared prefix: steps k < p only involve the leader's rows < p and everyone's rows >= p
+    if (sizeof(T) == 8 && right && takes_chain(h, c, g.cnt)) {
+        // a few evaluations on an fp64 handle: ONE persistent launch -- two chain workgroups per evaluation, everybody else pulls jobs
+        // (gpcc_chain.hip.h); its flag words are zeroed on the stream first
+        ProfScope pr(h, GPCC_PROF_SMALL_STEP, s);
+        const int si = g.slot0 / (h->ws_slots > 0 ? h->ws_slots : 1);
+        GpccChainArgs a;
+        a.words = h->d_chain_words + (long)si * h->chain_region_words;
+        a.ximg = h->d_ximg + (long)si * GPCC_CHAIN_MAX_EVALS * c.nt * GPCC_XIMG_ELEMS;
+        a.stepval = h->d_stepval + (long)si * GPCC_CHAIN_MAX_EVALS * c.nt * GPCC_CHAIN_STEPVALS;
+        a.trace = h->d_chain_trace ? h->d_chain_trace + (long)si * GPCC_CHAIN_MAX_EVALS * c.nt * 4 : nullptr;
+        a.ev_words = h->chain_ev_words;
+        a.qbase = h->chain_qbase;
+        const long used = ((long)a.qbase + (long)g.cnt * a.ev_words + 3) / 4 * 4;
+        (void)hipMemsetAsync(a.words, 0, sizeof(unsigned) * used, s);
+        const int ncb = 16 * ((g.cnt + 7) / 8);
+        long workers = (long)g.cnt * gpcc_chain_jobs(c.nt - 1);   // the widest step; more workgroups than that would only spin
+        const long room = (long)h->n_cus - 2 * g.cnt;
+        if (workers > room) workers = room;
+        if (workers < 1) workers = 1;
+        const long grid = (2L * g.cnt + workers > ncb) ? 2L * g.cnt + workers : ncb;   // (blocks of the chain range without a role work too)
+        gpcc_chain_kernel<<<(unsigned)grid, GPCC_CHAIN_THREADS, GPCC_CHAIN_LDS_BYTES, s>>>(c, g, a);
+        h->chain_count += g.cnt;
+        return;
+    }
     if (right && g.cnt <= h->fused_small_max && c.nt > 1) {
         // a few evaluations (the objective(alpha, rho) call site): diag(0), then per step the panel solve and ONE launch
         // that holds the trailing update of step k AND the diagonal step k+1 (gpcc_small_step): 2 nt - 1 launches
@@ -892,15 +917,6 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
     if (takes_fused_solve(h, c, g.cnt, concurrent)) {
         // left-looking, the panel solve inside the update (gpcc_update_solve): per step the diagonal tile first
         // (gpcc_syrk_diag: lower-triangle update + diagonal step in one workgroup per evaluation), then the rest of column k
-        if (h->step_fused && c.nrhs <= GPCC_DB_MAXRHS) {
-            // ONE launch per step: the workgroup that owns tile (k+1,k) goes on into the diagonal step of column k+1 (look-ahead,
-            // gpcc_step) while the rest of the launch takes the tiles below; launch -1 is the diagonal step of column 0
-            for (int k = -1; k < c.nt - 1; ++k) {
-                ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
-                gpcc_step<T><<<cnt8 * (k < 0 ? 1 : c.nt - k - 1), GPCC_GEMM_THREADS, GPCC_UPSOLVE_LDS_BYTES, s>>>(c, g, k);
-            }
-            return;
-        }
         for (int k = 0; k < c.nt; ++k) {
             {
                 ProfScope pr(h, GPCC_PROF_DIAG, s);
@@ -908,8 +924,8 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
             }
             if (k < c.nt - 1) {
                 ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
-                if (c.fold_mixed) gpcc_update_solve<T, true, true><<<cnt8 * (c.nt - k - 1), GPCC_GEMM_THREADS, GPCC_UPSOLVE_LDS_BYTES, s>>>(c, g, k);
-                else gpcc_update_solve<T, true><<<cnt8 * (c.nt - k - 1), GPCC_GEMM_THREADS, GPCC_UPSOLVE_LDS_BYTES, s>>>(c, g, k);
+                if (c.fold_mixed) gpcc_update_solve<T, true><<<cnt8 * (c.nt - k - 1), GPCC_GEMM_THREADS, GPCC_UPSOLVE_LDS_BYTES, s>>>(c, g, k);
+                else gpcc_update_solve<T, false><<<cnt8 * (c.nt - k - 1), GPCC_GEMM_THREADS, GPCC_UPSOLVE_LDS_BYTES, s>>>(c, g, k);
             }
         }
         return;
@@ -932,73 +948,46 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
         if (n > c.nt - 1) n = c.nt - 1;                                                      // (right-looking from step 1 on)
         if (n >= 2) ks = c.nt - n;
     }
-    // Look-ahead in the right-looking steps (round 4): the trailing update of step k is issued as "column k + 1 first" and "the rest";
-    // the diagonal step and the panel solve of column k + 1 -- a serial chain of two small launches, a fifth of a 16-evaluation group's
-    // time -- then run on a helper stream BESIDE the rest.  Unlike beside a full group's update, here the chain's few
-    // workgroups get CUs of their own.  Same jobs, same arithmetic: bitwise the results without it.
-    hipStream_t sla = nullptr;
-    hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    const bool la = h->look_ahead && !h->prof && !p && c.nt_fact == c.nt && ks < c.nt - 1 && find_helper(h, s, &sla, &ev_a, &ev_b);
     auto launch_diag = [&](int k, hipStream_t st) {
         ProfScope pr(h, GPCC_PROF_DIAG, st);
-        if (h->diag_blocks && c.nrhs <= GPCC_DB_MAXRHS) gpcc_diag_factor2<T><<<(k < p) ? 1 : g.cnt, GPCC_DIAG_THREADS, GPCC_DB_LDS_BYTES, st>>>(c, g, k);
-        else gpcc_diag_factor<T><<<(k < p) ? 1 : g.cnt, GPCC_DIAG_THREADS, GPCC_DIAG_LDS_BYTES, st>>>(c, g, k);
+        gpcc_diag_factor<T><<<(k < p) ? 1 : g.cnt, GPCC_DIAG_THREADS, GPCC_DIAG_LDS_BYTES, st>>>(c, g, k);
     };
     auto launch_trsm = [&](int k, hipStream_t st) {
         ProfScope pr(h, GPCC_PROF_TRSM, st);
         const int grid = (k < p) ? cnt8 * (c.nt - p) + (p - k - 1) : cnt8 * (c.nt - k - 1);
-        if (!p && g.cnt * (c.nt - k - 1) <= h->trsm_rows_jobs)   // few jobs: quarter-tile jobs on four times as many CUs
-            gpcc_panel_trsm_rows<T><<<g.cnt * (c.nt - k - 1) * 4, 512, GPCC_TRSM_ROWS_LDS_BYTES, st>>>(c, g, k);
-        else if (grid > 0) gpcc_panel_trsm<T><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, st>>>(c, g, k);
+        if (grid > 0) gpcc_panel_trsm<T><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, st>>>(c, g, k);
     };
-    auto launch_right = [&](int grid, hipStream_t st, int k, int ktiles, int kcol, int part) {   // (only a launch whose K loop starts at column 0 folds)
-        if (c.fold_mixed && kcol == 0) gpcc_panel_update<T, true, true><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, st>>>(c, g, k, ktiles, kcol, part);
-        else gpcc_panel_update<T, true><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, st>>>(c, g, k, ktiles, kcol, part);
+    auto launch_right = [&](int grid, hipStream_t st, int k, int ktiles, int kcol) {   // (only a launch whose K loop starts at column 0 folds)
+        if (c.fold_mixed && kcol == 0) gpcc_panel_update<T, true, true><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, st>>>(c, g, k, ktiles, kcol);
+        else gpcc_panel_update<T, true><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, st>>>(c, g, k, ktiles, kcol);
     };
     for (int k = 0; k < c.nt_fact; ++k) {
         const bool rstep = k >= ks;
         if (k > 0 && !rstep) {
             ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
             const int grid = (k < p) ? cnt8 * (c.nt - p) + (p - k) : cnt8 * (c.nt - k);
-            if (h->update_t && !p && c.nt_fact == c.nt) gpcc_update_solve<T, false><<<grid, GPCC_GEMM_THREADS, GPCC_UPSOLVE_LDS_BYTES, s>>>(c, g, k);
-            else if (c.fold_mixed) gpcc_panel_update<T, false, true><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, k, 0, 0);
-            else gpcc_panel_update<T, false><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, k, 0, 0);
+            if (c.fold_mixed) gpcc_panel_update<T, false, true><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, k, 0);
+            else gpcc_panel_update<T, false><<<grid, GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, k, 0);
         }
         if (k > 0 && k == ks) {   // catch-up: all trailing tiles (I,J), I >= J >= ks, minus their sums over columns 0 .. ks-1
             ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
             const int n = c.nt - k;
-            launch_right(cnt8 * (n * (n + 1) / 2), s, k - 1, k, 0, 0);
+            launch_right(cnt8 * (n * (n + 1) / 2), s, k - 1, k, 0);
         }
-        if (!(la && k > ks)) {   // (with look-ahead, the chain of a right-looking step k > ks was issued by step k - 1)
-            launch_diag(k, s);
-            if (k < c.nt - 1) launch_trsm(k, s);
-        }
+        launch_diag(k, s);
+        if (k < c.nt - 1) launch_trsm(k, s);
         if (rstep && k < c.nt - 1) {
             const int n = c.nt - k - 1;
-            if (la) {
-                // the CHAIN stays on this stream (in order: the diagonal step's workgroups, which need a whole CU's LDS, are placed the
-                // moment column k + 1 is done -- on a helper stream they arrive a few microseconds after the rest has taken every CU and
-                // wait until it has drained: profiles/r04/look_ahead_first_form_timeline.log); the REST goes to the low-priority helper
-                launch_right(cnt8 * n, s, k, 1, k, 1);
-                if (n >= 2) {
-                    (void)hipEventRecord(ev_a, s);
-                    (void)hipStreamWaitEvent(sla, ev_a, 0);
-                    launch_right(cnt8 * ((n - 1) * n / 2), sla, k, 1, k, 2);
-                    (void)hipEventRecord(ev_b, sla);
-                }
-                launch_diag(k + 1, s);
-                if (k + 1 < c.nt - 1) launch_trsm(k + 1, s);
-                if (n >= 2) (void)hipStreamWaitEvent(s, ev_b, 0);
-            } else {
+            {
                 ProfScope pr(h, GPCC_PROF_PANEL_UPDATE, s);
-                launch_right(cnt8 * (n * (n + 1) / 2), s, k, 1, k, 0);
+                launch_right(cnt8 * (n * (n + 1) / 2), s, k, 1, k);
             }
         }
     }
     // augmented systems: Schur complement of the rows beyond the factorised columns,
     // S = C - V^T V with V = L^-1 [cross block]  
     for (int k = c.nt_fact; k < c.nt; ++k)
-        gpcc_panel_update<T, false><<<cnt8 * (c.nt - k), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, c.nt_fact, 0, 0);
+        gpcc_panel_update<T, false><<<cnt8 * (c.nt - k), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, c.nt_fact, 0);
 }
 
 // left-looking blocked Cholesky + fused forward solve (+ Schur complement of non-factorised rows)
@@ -1057,6 +1046,13 @@ static int enqueue_batch(gpcc_handle_t h, int M, const double *d_delays, const d
     int rc = ensure_workspace(h);
     if (rc) return rc;
     if (!h->share_now) h->share_now = (h->shared_prefix == 2);   // device pointers cannot be inspected: only on assertion
+    if (h->chain_max > 0 && h->precision == GPCC_PRECISION_FP64 && h->nt > 1) {
+        const int tail = (M % h->ws_slots) ? M % h->ws_slots : h->ws_slots;   // (only a batch's last group can be this small)
+        if (tail <= h->chain_max && tail <= h->right_looking_max) {
+            rc = ensure_chain(h);
+            if (rc) return rc;
+        }
+    }
     const GpccCtx c = make_ctx(h);
     const int S = h->prof ? 1 : h->ws_streams;  // profiling serialises groups onto one stream
     const int cs = h->ws_slots;
@@ -1082,7 +1078,7 @@ static int enqueue_batch(gpcc_handle_t h, int M, const double *d_delays, const d
         bool split = h->split_min > 0 && g.cnt >= h->split_min && g.cnt <= h->split_max && h->nt >= h->split_nt_min;
         if (h->split_min > 0 && h->split_small && g.cnt < h->split_min)
             split = (g.cnt > h->right_looking_max && g.cnt < 24 && (h->nt <= 16 || (h->nt <= 24 && g.cnt < 20))) || (g.cnt >= 6 && g.cnt <= h->right_looking_max && h->nt >= 24);
-        split = split && !h->prof && !cg.share_p && g.cnt >= 2 && h->nt > 1;
+        split = split && !h->prof && !cg.share_p && g.cnt >= 2 && h->nt > 1 && !takes_chain(h, cg, g.cnt);
         if (split) {
             GpccGroup ga = g, gb = g;
             ga.cnt = g.cnt >= 24 ? 8 * ((g.cnt + 15) / 16) : (g.cnt + 1) / 2;   // (multiples of 8 keep an evaluation's workgroups on one XCD)
@@ -1109,8 +1105,6 @@ static int enqueue_batch(gpcc_handle_t h, int M, const double *d_delays, const d
         for (int s = 0; s < h->ws_streams; ++s) {
             if (h->str[s]) (void)hipStreamSynchronize(h->str[s]);
             if (h->str2[s]) (void)hipStreamSynchronize(h->str2[s]);
-            for (int j = 0; j < 2; ++j)
-                if (h->str_la[s][j]) (void)hipStreamSynchronize(h->str_la[s][j]);
         }
         (void)hipGetLastError();
         h->err = msg;
@@ -1364,6 +1358,10 @@ extern "C" int gpcc_loglik_batch(gpcc_handle_t h, int M, const double *delays, c
     HIPCHK(h, hipMemcpyAsync(loglik, h->d_out, sizeof(double) * M, hipMemcpyDeviceToHost, h->main_stream));
     HIPCHK(h, hipMemcpyAsync(info, h->d_oinfo, sizeof(int) * M, hipMemcpyDeviceToHost, h->main_stream));
     HIPCHK(h, hipStreamSynchronize(h->main_stream));
+    for (int i = 0; i < M; ++i)
+        if (info[i] == GPCC_INFO_TIMEOUT)
+            return fail(h, GPCC_ERR_STATE, "the persistent few-evaluation launch was abandoned (a bounded wait expired: evaluation %d); "
+                                           "gpcc_set_option(handle, \"chain_max\", 0) selects the launch-per-step path", i);
     return 0;
 }
 
@@ -2371,6 +2369,25 @@ static void prof_collect(gpcc_handle_t h)
         hipEventDestroy(r.b);
     }
     h->recs.clear();
+}
+
+// the stamps of the last persistent launch on workspace stream 0 (option "chain_trace"), microseconds from the first one
+extern "C" int gpcc_chain_trace(gpcc_handle_t h, int evaluation, double *out_us, int capacity)
+{
+    if (!h || !out_us) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
+    h = primary(h);
+    if (!h->d_chain_trace) return fail(h, GPCC_ERR_STATE, "no trace: set option \"chain_trace\" to 1 before the evaluation");
+    if (evaluation < 0 || evaluation >= GPCC_CHAIN_MAX_EVALS || capacity < 4 * h->nt) return fail(h, GPCC_ERR_ARGUMENT, "evaluation %d / capacity %d (need 4 nt = %d)", evaluation, capacity, 4 * h->nt);
+    GPCC_ON_DEVICE(h, h->device);
+    HIPCHK(h, hipDeviceSynchronize());
+    std::vector<unsigned long long> st(4 * (size_t)h->nt);
+    HIPCHK(h, hipMemcpy(st.data(), h->d_chain_trace + (long)evaluation * h->nt * 4, sizeof(unsigned long long) * st.size(), hipMemcpyDeviceToHost));
+    int khz = 100000;
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device);
+    unsigned long long t0 = ~0ull;
+    for (unsigned long long v : st) if (v && v < t0) t0 = v;
+    for (size_t i = 0; i < st.size(); ++i) out_us[i] = st[i] ? (double)(st[i] - t0) * 1e3 / khz : -1.0;
+    return 0;
 }
 
 extern "C" int gpcc_profile_enable(gpcc_handle_t h, int on)

@@ -70,8 +70,7 @@ struct GpccCtx {
     int *info;       // slots
     double *gpart;   // slots x nt(nt+1)/2 x nrhs^2 : per-tile partial sums of X' K0 X (fp32 refinement, gpcc_refine_partials)
     int linv_keep;   // 1: linv holds ALL nt inverses of a slot (slot*nt + k), kept for the backward solve of the fp32
-                     //    refinement; 0: one tile per slot, overwritten every step; 2: two tiles per slot, steps alternate
-                     //    (gpcc_step writes inv(L_{k+1,k+1}) while the other jobs of its launch still read inv(L_kk))
+                     //    refinement; 0: one tile per slot, overwritten every step
     double *kdiag;   // slots x Np : diag(K) as assembled, fp64 (fp32 mode only: numerator of the pivot ratios below)
     double *cond;    // slots x 2  : sum_i K_ii / d_i and max_i K_ii / d_i over the pivots d_i (fp32 mode only) -- the
                      //              a-posteriori conditioning measure behind the fp64 re-evaluation, DESIGN.md 4.7
@@ -130,7 +129,7 @@ __device__ __forceinline__ long gpcc_tile_off(int I, int J)
 }
 __device__ __forceinline__ long gpcc_linv_off(const GpccCtx &c, int slot, int k)
 {
-    return (c.linv_keep == 1 ? ((long)slot * c.nt + k) : c.linv_keep == 2 ? ((long)slot * 2 + (k & 1)) : (long)slot) * GPCC_TILE_ELEMS;
+    return (c.linv_keep == 1 ? ((long)slot * c.nt + k) : (long)slot) * GPCC_TILE_ELEMS;
 }
 // Slot swizzle of row r (depends on row bits 1..3).  ds_read_b128 is served in 16-lane groups
 // {q even, rows 0-3,12-15 | q odd, rows 4-11} (and the mirrored one); g maps the row pairs
@@ -359,14 +358,18 @@ __device__ __forceinline__ bool gpcc_sep_point(double u, double c, double s, dou
     return fabs(p) <= GPCC_SEP_MAX;
 }
 // the element from the separable factors: aa' k(u_i, u_j) with t = s |u_i - u_j|   (KID 0 OU, 2 Matern-3/2, 3 Matern-5/2)
+// (contract(off): the multiplications below carry no `contract` flag, so no caller can fuse its own addition -- the B term, say -- into
+//  them: an element has the same bits wherever it is evaluated -- assembly, fold, refinement, small-N kernels --, whatever the compiler
+//  version; the fmas the element is meant to have are written out)
 template <int KID>
 __device__ __forceinline__ double gpcc_sep_eval(double ui, double uj, double Ai, double Bi, double Aj, double Bj, double s)
 {
+#pragma clang fp contract(off)
     const double e = fmin(Ai * Bj, Aj * Bi);
     if (KID == 0) return e;
     const double t = fabs(ui - uj) * s;
-    if (KID == 2) return fma(e, t, e);
-    return e * fma(t, fma(t, 1.0 / 3.0, 1.0), 1.0);
+    if (KID == 2) return __builtin_fma(e, t, e);
+    return e * __builtin_fma(t, __builtin_fma(t, 1.0 / 3.0, 1.0), 1.0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -911,11 +914,8 @@ __device__ __forceinline__ void gpcc_dma_chunk(const T *gA, const T *gB, T *stag
 // kcol = first tile column of the K loop: 0 for the left-looking form, k for a right-looking step.  RIGHT with kcol = 0 and
 // ktiles = k + 1 is the CATCH-UP of a group that switches from left- to right-looking at step k + 1: every trailing tile
 // (I,J), I >= J > k, receives the whole sum over the finished columns 0..k at once.
-// part (RIGHT only; look-ahead, round 4): 0 = every trailing tile; 1 = the tiles of column k + 1 only -- what the diagonal step and the
-// panel solve of column k + 1 wait for; 2 = all the others (I >= J >= k + 2), which then run BESIDE that diagonal step on another
-// stream.  A tile's arithmetic is the same in every part.
 template <typename T, bool RIGHT, bool MIXED = false>
-__global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup g, int k, int ktiles, int kcol, int part)
+__global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup g, int k, int ktiles, int kcol)
 {
     typedef GpccPrec<T> P;
     constexpr int CH = GPCC_CHUNK_BYTES / sizeof(T);
@@ -927,7 +927,7 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
 
     const int nrem = c.nt - k - 1;
     const bool shared = !RIGHT && c.share_p > k;   // step inside the shared prefix: B operand = the leader's row k
-    const int per = RIGHT ? (part == 1 ? nrem : part == 2 ? (nrem - 1) * nrem / 2 : nrem * (nrem + 1) / 2) : (shared ? c.nt - c.share_p : c.nt - k);
+    const int per = RIGHT ? nrem * (nrem + 1) / 2 : (shared ? c.nt - c.share_p : c.nt - k);
     const int nmain = 8 * ((g.cnt + 7) / 8) * per;
     const int x = blockIdx.x & 7, qq = blockIdx.x >> 3;
     int m = g.spread ? (int)blockIdx.x % g.cnt : (qq / per) * 8 + x;
@@ -942,11 +942,8 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
     } else if (shared) {
         I = c.share_p + jt;
         J = k;
-    } else if (RIGHT && part == 1) {
-        I = k + 1 + jt;
-        J = k + 1;
     } else if (RIGHT) {
-        const int j = jt, first = (part == 2) ? k + 2 : k + 1;
+        const int j = jt, first = k + 1;
         int a = (int)((sqrtf(8.0f * j + 1.0f) - 1.0f) * 0.5f);
         while (a * (a + 1) / 2 > j) --a;
         while ((a + 1) * (a + 2) / 2 <= j) ++a;
@@ -1079,12 +1076,11 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
 // spare accumulator.  The lower blocks of X (72 KiB in fp64) are DMA'd into LDS after the K-loop (80 KiB of LDS per
 // workgroup: still two workgroups per CU).  The result leaves through LDS in the tile's own byte layout, so the global
 // stores are linear 16-byte copies.
-// SOLVE = false: update only, tiles I >= k (drop-in for gpcc_panel_update<T, false>; used to A/B the transposed main loop).
-// grid 8 * ceil(cnt / 8) * (nt - k - (SOLVE ? 1 : 0)), block 512.
+// grid 8 * ceil(cnt / 8) * (nt - k - 1), block 512.
 // ------------------------------------------------------------------------------------------
 #define GPCC_UPSOLVE_LDS_BYTES (80 * 1024)
 // one job: tile (I,k) of evaluation `slot` (the whole workgroup; smem = GPCC_UPSOLVE_LDS_BYTES of LDS)
-template <typename T, bool SOLVE, bool MIXED = false>
+template <typename T, bool MIXED = false>
 __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const int k, const int I, const int slot, T *smem)
 {
     typedef GpccPrec<T> P;
@@ -1112,7 +1108,7 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
     // read from global memory, a lane's 96 loads of 8 bytes went out in register-limited batches, each a full memory latency --
     // the timing-only build without the initialisation was 7.8 % faster (N = 2048: 16 %), profiles/r04/timing_only_job_fixed_cost.log
     constexpr int VEC_OFF = 72 * 1024;
-    const bool staged = SOLVE && c.fold != 0;   // (uniform)
+    const bool staged = c.fold != 0;   // (uniform)
     if (staged) {
         const double *spk = c.sep + (long)slot * 4 * c.Np + k * GPCC_TILE;
         if (wave < 4) gpcc_dma_piece<0>(gpcc_uniform_ptr(spk + (long)wave * c.Np), (unsigned)lane * 16u, smem_addr + VEC_OFF + wave * 1024);
@@ -1130,18 +1126,10 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
     // operations per element = 0.5 % of the job's matrix work at the mean k, under the first chunk's LDS-DMA
     int fmode = 0;
     double bt = 0.0;
-#ifdef GPCC_TIMING_NO_INIT   /* timing-only: accumulators start at zero (WRONG results) */
-#pragma unroll
-    for (int cf = 0; cf < 8; ++cf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[cf][r] = 0;
-    if (false)
-#else
-    if (SOLVE && c.fold)
-#endif
+    if (c.fold)
         fmode = gpcc_fold_mode<T>(c, __builtin_amdgcn_readfirstlane(c.sepflag[(long)slot * c.nt + I]),
                                   __builtin_amdgcn_readfirstlane(c.sepflag[(long)slot * c.nt + k]), bt);
-    if (SOLVE && fmode != 0) {
+    if (fmode != 0) {
         const double *sp = c.sep + (long)slot * 4 * c.Np;
         const int ri = I * GPCC_TILE + wave * 16 + lr;
         // (this lane's row: four coalesced loads, issued before the wait)
@@ -1192,7 +1180,6 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
         for (int st = 0; st < 2; ++st) {  // stage st holds chunk ch2+st (nch is even)
             const int ch = ch2 + st;
             const int so = st * 2 * CH;
-#ifndef GPCC_TIMING_NO_DMA     /* timing-only diagnostic builds (tools/timing_variants.sh): WRONG results, never shipped */
             if (ch + 1 < nch)
                 gpcc_dma_chunk_at<T>(gI + (long)(ch + 1) * CH, gK + (long)(ch + 1) * CH, smem_addr + (st ^ 1) * 2 * GPCC_CHUNK_BYTES, wave, lane);
             typename P::v16 b[2];
@@ -1213,17 +1200,10 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
                         acc[4 * h + f] = P::mfma(a[f][s2 / P::EP][s2 % P::EP], b[s2 / P::EP][s2 % P::EP], acc[4 * h + f]);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifndef GPCC_TIMING_NO_BARRIER
             __syncthreads();
-#endif
         }
     }
-#endif
-#ifdef GPCC_TIMING_NO_SOLVE    /* timing-only diagnostic builds (tools/timing_variants2.sh): WRONG results, never shipped */
-    if (SOLVE && c.nt < 0) {
-#else
-    if (SOLVE) {
-#endif
+    {
         // ---- lower blocks of X = inv(L_kk) -> LDS, packed chunk by chunk: chunk ch2 of the tile holds columns KC ch2 .. of all
         // 128 rows; rows above the chunk's first column block are zero and skipped.  Block (i, cf) is then read at
         // xbase(cf) + rows 16 i ..: element (R, col) at xoff[chunk] + (R - R0[chunk]) KC + swizzled slot.
@@ -1238,14 +1218,12 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
                 o += (GPCC_TILE - 16 * FPC * ch) * P::KC;     // rows 16 FPC ch .. 127
             }
         }
-#ifndef GPCC_TIMING_NO_XLOAD
 #pragma unroll
         for (int ch = 0; ch < P::NCH; ++ch) {
             const int r0x = 16 * FPC * ch, npiece = (GPCC_TILE - r0x) * P::KC / PIECE;   // 1 KiB pieces of this chunk's lower rows
             for (int pc = __builtin_amdgcn_readfirstlane(wave); pc < npiece; pc += 8)
                 gpcc_dma_piece<0>(gpcc_uniform_ptr(gX + (long)ch * CH + r0x * P::KC + pc * PIECE), (unsigned)lane * 16u, gpcc_lds_addr(smem + xoff[ch] + pc * PIECE));
         }
-#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         auto xload = [&](int i, int cf, T (&xa)[4]) {   // A operand of block (i, cf): X[16 i + lr][16 cf + crow(q, s2)], s2 = 0..3
@@ -1279,9 +1257,6 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
         }
         __syncthreads();   // every wave is done with X before the output staging overwrites it
     }
-#ifdef GPCC_TIMING_NO_STORE
-    if (c.nt >= 0) return;   // (timing-only: the compiler cannot drop the arithmetic, the job skips its output)
-#endif
     // ---- out through LDS in the tile's own byte layout (rows 64 h .. 64 h + 63 of every chunk = 64 KiB in fp64), then linear
     // 16-byte copies to global; L = -acc (resp. T' = -acc)
     constexpr int HALVES = (int)(sizeof(T) * GPCC_TILE_ELEMS / 65536);   // fp64: 2, fp32: 1
@@ -1308,7 +1283,7 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
         }
         if (hv + 1 < HALVES) __syncthreads();
     }
-    if (SOLVE) {
+    {
         // forward substitution of logpdf's whitening: z_I[r] -= sum_c L(I,k)[r][c] w_k[c]; a wave owns its 16 rows completely
         for (int j = 0; j < c.nrhs; ++j) {
             double *zp = c.z + ((long)slot * c.nrhs + j) * c.Np + I * GPCC_TILE;
@@ -1333,21 +1308,18 @@ __device__ __forceinline__ void gpcc_update_solve_job(const GpccCtx &c, const in
     }
 }
 
-template <typename T, bool SOLVE, bool MIXED = false>
+template <typename T, bool MIXED = false>
 __global__ __launch_bounds__(512, 4) void gpcc_update_solve(GpccCtx c, GpccGroup g, int k)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int per = c.nt - k - (SOLVE ? 1 : 0);
+    const int per = c.nt - k - 1;
     const int x = blockIdx.x & 7, qq = blockIdx.x >> 3;
     const int m = g.spread ? (int)blockIdx.x % g.cnt : (qq / per) * 8 + x;
     if (m >= g.cnt) return;
-    const int I = k + (SOLVE ? 1 : 0) + (g.spread ? (int)blockIdx.x / g.cnt : qq % per);
+    const int I = k + 1 + (g.spread ? (int)blockIdx.x / g.cnt : qq % per);
     const int slot = g.slot0 + m;
-#if !defined(GPCC_TIMING_NO_DMA) && !defined(GPCC_TIMING_NO_LDSREAD) && !defined(GPCC_TIMING_NO_BARRIER) && !defined(GPCC_TIMING_NO_XLOAD) && \
-    !defined(GPCC_TIMING_NO_SOLVE) && !defined(GPCC_TIMING_NO_STORE) && !defined(GPCC_TIMING_NO_INIT)   /* (timing-only builds keep going on garbage) */
     if (c.info[slot] != 0) return;
-#endif
-    gpcc_update_solve_job<T, SOLVE, MIXED>(c, k, I, slot, (T *)smem_raw);
+    gpcc_update_solve_job<T, MIXED>(c, k, I, slot, (T *)smem_raw);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2039,7 +2011,8 @@ __global__ __launch_bounds__(GPCC_DIAG_THREADS) void gpcc_diag_factor(GpccCtx c,
 // Wave-specialised: NA blocks (RA, CA..CA+NA-1) and NB blocks (RB, CB..CB+NB-1).  ONE operand stream (both MFMA operands are
 // fragments of the same tile row) through a 4-stage LDS ring with one barrier per chunk; the updated blocks (rounded to T, as the
 // unfused path stores them) end up in the diagonal step's LDS image.  Used by gpcc_small_step (K = one tile) and gpcc_syrk_diag.
-// BLK: the result goes into the packed 16 x 16 block image of gpcc_diag_blocks (gpcc_bi / gpcc_be) instead of the 128 x LD image.
+// BLK: the result goes into the packed 16 x 16 block image of the few-evaluation chain kernel (gpcc_chain.hip.h: gpcc_bi / gpcc_be) instead of
+// the 128 x LD image.
 __device__ __forceinline__ int gpcc_bi(int i, int j) { return (i * (i + 1) / 2 + j) * 256; }   // block (i, j), j <= i, in doubles
 __device__ __forceinline__ int gpcc_be(int r, int c)                                              // element (r, c) of a block
 {
@@ -2241,503 +2214,6 @@ __global__ __launch_bounds__(512) void gpcc_syrk_diag(GpccCtx c, GpccGroup g, in
         }
     }
     gpcc_diag_body<T, true>(c, g, k, m, smem_d);   // (a failed evaluation is reported there)
-}
-
-// ------------------------------------------------------------------------------------------
-// gpcc_diag_blocks: the diagonal step on HALF a CU's LDS (round 4).  gpcc_diag_body keeps the 128 x 128 tile as a padded square
-// (133 KiB) plus the eight inverted diagonal blocks -- 158.7 KiB, a whole CU, so nothing can run beside it.  Here the image is the
-// LOWER TRIANGLE only, 36 blocks of 16 x 16 doubles (72 KiB), and the inverse is built IN PLACE (LAPACK dtrtri's trick, block-wise):
-//   * block (i, j), j <= i, at gpcc_bi(i, j); element (r, c) of a block at gpcc_be(r, c): physical row r ^ bit2(r), the sixteen
-//     8-byte slots of a row XOR-ed with 2 (row >> 1) -- no padding, and both MFMA fragment patterns (A operand: lane (lr, q) reads
-//     [lr][q + 4 s]; B operand / accumulator: [q + 4 s][lr] resp. [crow(q, r)][lr], fp64 and fp32 register maps) are conflict-free;
-//   * a diagonal block holds D_b until wave 0 has factored it and inv(L_D)^T afterwards (L_D itself is read by nobody: the panel
-//     multiplies by inv(L_D), sum log L_ii comes from the register factorisation; store_l sends it straight to global memory);
-//   * row i of inv(L) -- X[i][j] = -inv(D_i) sum_{m=j}^{i-1} L[i][m] X[m][j] -- reads ALL of L's row i and nothing else of row i is
-//     read later (the trailing update of column block i-1.. has been applied), so after one barrier X[i][j] overwrites L[i][j].
-// Same arithmetic in the same order as gpcc_diag_body (same task split, same MFMA chains): the two return the same bits.
-// LDS: 36 x 2 KiB + nrhs x 1 KiB (nrhs <= GPCC_DB_MAXRHS) + 2 KiB + the Gram matrix <= GPCC_UPSOLVE_LDS_BYTES, so the step can
-// live INSIDE the update's launch (gpcc_step) or beside another kernel's workgroup on the same CU.
-// ------------------------------------------------------------------------------------------
-#define GPCC_DB_MAXRHS 4
-#define GPCC_DB_LDS_BYTES ((36 * 256 + GPCC_DB_MAXRHS * GPCC_TILE + 2 * GPCC_TILE + GPCC_DB_MAXRHS * GPCC_DB_MAXRHS + 1) * 8 + 16)
-static_assert(GPCC_DB_LDS_BYTES <= GPCC_UPSOLVE_LDS_BYTES, "gpcc_diag_blocks must fit half a CU's LDS");
-
-#define GPCC_OPAQUE_LANE(a, b) asm volatile("" : "+v"(a), "+v"(b))
-template <typename T, bool PRELOADED>
-__device__ __forceinline__ void gpcc_diag_blocks(const GpccCtx &c, const GpccGroup &g, const int k, const int m, double *smem)
-{
-    typedef GpccPrec<T> P;
-    typedef GpccPrec<double> PD;
-    double *sB = smem;                                  // 36 blocks (see above)
-    double *sz = sB + 36 * 256;                         // nrhs x 128: Z_k, later W_k
-    double *sr = sz + GPCC_DB_MAXRHS * GPCC_TILE;       // [0, 80): wave 0's column scratch; [96, 128): per-block statistics
-    double *skd = sr + GPCC_TILE;                       // diag(K) of this block's rows as assembled (fp32 mode)
-    double *sG = skd + GPCC_TILE;                       // nrhs x nrhs Gram matrix
-    double *sld = sG + GPCC_DB_MAXRHS * GPCC_DB_MAXRHS; // sum log L_ii of this block
-    int *sbad = (int *)(sld + 1);
-
-    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int NWK = 6;
-    const int wk = (wave == 0 || wave == 4) ? -1 : (wave < 4 ? wave - 1 : wave - 2);
-    const int slot = g.slot0 + m, nrhs = c.nrhs;
-    const bool last = (k == c.nt_fact - 1);
-    int inf = c.info[slot];
-    if (inf == 0 && m > 0) inf = gpcc_leader_failure(c, g);
-    if (inf != 0) {
-        if (last && tid == 0) {
-            g.out_loglik[g.first + m] = __builtin_nan("");
-            g.out_info[g.first + m] = inf;
-        }
-        return;
-    }
-    T *tiles = (T *)c.tiles + (long)slot * c.slot_stride;
-    T *Tt = tiles + gpcc_tile_off(k, k);
-    constexpr int NPIECE = GPCC_TILE_ELEMS / P::EP;
-    constexpr int NT = GPCC_DIAG_THREADS;
-    constexpr int UL = (NPIECE / NT < 8) ? NPIECE / NT : 8;   // loads in flight per thread
-    static_assert(NPIECE % (NT * UL) == 0, "tile pieces must divide evenly over the threads");
-    if (!PRELOADED)
-        for (int p0 = tid; p0 < NPIECE; p0 += NT * UL) {   // the lower 36 blocks of the tile -> image
-            typename P::v16 v[UL];
-#pragma unroll
-            for (int u = 0; u < UL; ++u) {
-                const int e = (p0 + NT * u) * P::EP;
-                const int ch = e / (GPCC_TILE * P::KC), rem = e % (GPCC_TILE * P::KC), r = rem / P::KC, ks = rem % P::KC;
-                const int col0 = ch * P::KC + ((ks / P::EP) ^ gpcc_sw(r)) * P::EP;
-                if ((col0 >> 4) <= (r >> 4)) v[u] = *(const typename P::v16 *)(Tt + e);
-            }
-#pragma unroll
-            for (int u = 0; u < UL; ++u) {
-                const int e = (p0 + NT * u) * P::EP;
-                const int ch = e / (GPCC_TILE * P::KC), rem = e % (GPCC_TILE * P::KC), r = rem / P::KC, ks = rem % P::KC;
-                const int col0 = ch * P::KC + ((ks / P::EP) ^ gpcc_sw(r)) * P::EP;
-                if ((col0 >> 4) <= (r >> 4)) {
-#pragma unroll
-                    for (int h = 0; h < P::EP; ++h)
-                        sB[gpcc_bi(r >> 4, col0 >> 4) + gpcc_be(r & 15, (col0 & 15) + h)] = (double)v[u][h];
-                }
-            }
-        }
-    for (int e = tid; e < nrhs * GPCC_TILE; e += NT)
-        sz[e] = c.z[((long)slot * nrhs + e / GPCC_TILE) * c.Np + k * GPCC_TILE + (e % GPCC_TILE)];
-    if (tid == 0) *sbad = 0;
-    const bool track = sizeof(T) == 4 && c.kdiag != nullptr;
-    if (track && tid < GPCC_TILE) skd[tid] = c.kdiag[(long)slot * c.Np + k * GPCC_TILE + tid];
-    const bool store_l = c.store_l != 0;
-
-    __syncthreads();
-    for (int jb = 0; jb <= 8; ++jb) {
-        const int r0 = jb * 16;
-        int lrv = lr, qv = q;   // opaque per-phase copies: keeps the compiler from hoisting every lane-dependent address of all nine rounds out of the loop (> 256 VGPRs)
-        GPCC_OPAQUE_LANE(lrv, qv);
-        d4 xo[2];            // rows of inv(L) built in this round: written after the barrier (in place of L's row)
-        int xj[2] = {-1, -1};
-        if (wave == 0) {
-            if (jb > 0 && jb < 8) {   // C(jb-1) for the block the factorisation below needs: D_jb -= P_jb P_jb^T
-                d4 x;
-                double pa[4], pb[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x[r] = sB[gpcc_bi(jb, jb) + gpcc_be(qv + 4 * r, lrv)];
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) {
-                    pb[s2] = sB[gpcc_bi(jb, jb - 1) + gpcc_be(lrv, qv + 4 * s2)];
-                    pa[s2] = -pb[s2];
-                }
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) x = PD::mfma(pa[s2], pb[s2], x);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sB[gpcc_bi(jb, jb) + gpcc_be(qv + 4 * r, lrv)] = x[r];
-            }
-            if (jb < 8) {
-                // ---- (A) 16x16 potf2 + inverse in registers (see gpcc_diag_body): lanes 0-15 own the rows of D, lanes 16-31 the
-                // columns of inv(L_D); ONE right-looking instruction stream for both
-                const bool xl = qv != 0;
-                double v[16];
-                double *blk = sB + gpcc_bi(jb, jb);
-#pragma unroll
-                for (int cc = 0; cc < 16; ++cc) v[cc] = xl ? ((cc == lrv) ? 1.0 : 0.0) : blk[gpcc_be(lrv, cc)];
-                int bad = 0;
-                double py = 1.0;
-                int pe = 0;
-                double rs = 0.0, rm = 0.0;
-                // software-pipelined like gpcc_small_potf2: the broadcast column of pivot j is fetched (cn) and applied to columns
-                // >= j+2 during the reciprocal square root of pivot j+1 -- only column j+1 (through v_readlane) is on the
-                // pivot-to-pivot chain.  Every element still receives its updates in ascending pivot order: same bits.
-                double cn[16];
-#pragma unroll
-                for (int cc = 0; cc < 16; ++cc) cn[cc] = 0.0;
-                double d = gpcc_bcast(v[0], 0), vp = 0.0;
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    if (!(d > 0.0) && bad == 0) bad = j + 1;
-                    const double y = gpcc_rsqrt(d);
-                    if (j >= 1) {   // the rest of pivot j-1's rank-1 update (column j had its share through the readlane below)
-#pragma unroll
-                        for (int cc = j + 1; cc < 16; ++cc) {
-                            v[cc] = __builtin_fma(-vp, cn[cc], v[cc]);
-                            asm volatile("" : "+v"(v[cc]));   // applied NOW (left alone the compiler sinks the updates to their readers
-                                                              // and keeps every broadcast column alive: > 256 VGPRs)
-                        }
-                    }
-                    py *= __builtin_amdgcn_frexp_mant(y);
-                    pe += __builtin_amdgcn_frexp_exp(y);
-                    if (sizeof(T) == 4 && track) {
-                        const double ratio = skd[r0 + j] * (y * y);
-                        rs += ratio;
-                        rm = fmax(rm, ratio);
-                    }
-                    v[j] *= y;
-                    if (j < 15) {
-                        sr[qv == 0 ? lrv : 16 + lane] = v[j];
-                        const double lnx = gpcc_bcast(v[j], j + 1);
-                        v[j + 1] = __builtin_fma(-v[j], lnx, v[j + 1]);
-                        d = gpcc_bcast(v[j + 1], j + 1);
-                        vp = v[j];
-#pragma unroll
-                        for (int cc = j + 2; cc < 16; ++cc) cn[cc] = sr[cc];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (lane < 32) {
-                    if (xl) {   // column lrv of X = inv(L_D) as row lrv of the block: the block now holds inv(L_D)^T
-#pragma unroll
-                        for (int cc = 0; cc < 16; ++cc) blk[gpcc_be(lrv, cc)] = v[cc];
-                    } else if (store_l) {   // row lrv of L_D straight to the tile (dense factor export only)
-#pragma unroll
-                        for (int cc = 0; cc < 16; ++cc) Tt[gpcc_elem_off<T>(r0 + lrv, r0 + cc)] = (T)((cc <= lrv) ? v[cc] : 0.0);
-                    }
-                    if (lane == 0 && bad && *sbad == 0) *sbad = r0 + bad;
-                    if (lane == 0) {
-                        sr[96 + jb] = py;
-                        sr[104 + jb] = (double)pe;
-                        sr[112 + jb] = rs;
-                        sr[120 + jb] = rm;
-                    }
-                }
-            }
-        } else if (wk >= 0 && jb > 0) {
-            const int jp = jb - 1;
-            // ---- (C) rest of the trailing update of column block jp
-            const int nb = 7 - jp, ntri = nb * (nb + 1) / 2;
-            for (int t0 = 1 + wk; t0 < ntri; t0 += 2 * NWK) {
-                int rfv[2], cfv[2];
-                bool on[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int tt = t0 + NWK * u;
-                    on[u] = tt < ntri;
-                    const int te = on[u] ? tt : t0;
-                    const int rr = (te >= 1) + (te >= 3) + (te >= 6) + (te >= 10) + (te >= 15) + (te >= 21);
-                    rfv[u] = jp + 1 + rr;
-                    cfv[u] = jp + 1 + te - rr * (rr + 1) / 2;
-                }
-                d4 x[2];
-                double pa[2][4], pb[2][4];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) x[u][r] = sB[gpcc_bi(rfv[u], cfv[u]) + gpcc_be(qv + 4 * r, lrv)];
-#pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2) {
-                        pa[u][s2] = -sB[gpcc_bi(rfv[u], jp) + gpcc_be(lrv, qv + 4 * s2)];
-                        pb[u][s2] = sB[gpcc_bi(cfv[u], jp) + gpcc_be(lrv, qv + 4 * s2)];
-                    }
-                }
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) {
-                    x[0] = PD::mfma(pa[0][s2], pb[0][s2], x[0]);
-                    x[1] = PD::mfma(pa[1][s2], pb[1][s2], x[1]);
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    if (on[u]) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) sB[gpcc_bi(rfv[u], cfv[u]) + gpcc_be(qv + 4 * r, lrv)] = x[u][r];
-                    }
-            }
-        }
-        GPCC_OPAQUE_LANE(lrv, qv);
-        if (jb > 0) {
-            // ---- (X) row i = jb-1 of inv(L) and (W) rows i of W_k, one task per worker (gpcc_diag_body's split)
-            const int i = jb - 1;
-            bool dow = false;
-            int j0 = -1, j1 = -1;
-            if (jb == 8) {
-                dow = wave == 0;
-                j0 = wave - 1;
-            } else if (wk >= 0) {
-                dow = wk == 0;
-                j0 = wk - 1;
-                j1 = (wk == NWK - 1) ? NWK - 1 : -1;
-            }
-            if (dow) {
-                const int zrow = (lrv < nrhs) ? lrv : 0;
-                d4 S, S1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double zv = sz[zrow * GPCC_TILE + i * 16 + qv + 4 * r];
-                    S[r] = (lrv < nrhs) ? -zv : 0.0;
-                }
-                for (int mm = 0; mm < i; ++mm) {
-#pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2) {
-                        const double av = sB[gpcc_bi(i, mm) + gpcc_be(lrv, qv + 4 * s2)];      // L[i][mm]
-                        const double wv = sz[zrow * GPCC_TILE + mm * 16 + qv + 4 * s2];
-                        const double bv = (lrv < nrhs) ? wv : 0.0;
-                        if (s2 & 1) S1 = PD::mfma(av, bv, S1);
-                        else S = PD::mfma(av, bv, S);
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) S[r] += S1[r];
-                d4 Y = {0.0, 0.0, 0.0, 0.0}, Y1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double dv = -sB[gpcc_bi(i, i) + gpcc_be(qv + 4 * r, lrv)];           // inv(D_i)[lrv][qv + 4 r]
-                    if (r & 1) Y1 = PD::mfma(dv, S[r], Y1);
-                    else Y = PD::mfma(dv, S[r], Y);
-                }
-                if (lrv < nrhs) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sz[lrv * GPCC_TILE + i * 16 + qv + 4 * r] = Y[r] + Y1[r];
-                }
-            }
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int j = n ? j1 : j0;
-                if (j < 0 || j >= i) continue;
-                d4 S = {0.0, 0.0, 0.0, 0.0}, S1 = {0.0, 0.0, 0.0, 0.0};
-                for (int mm = j; mm < i; ++mm) {
-#pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2) {
-                        const double av = sB[gpcc_bi(i, mm) + gpcc_be(lrv, qv + 4 * s2)];                     // L[i][mm]
-                        const double bv = (mm == j) ? sB[gpcc_bi(j, j) + gpcc_be(lrv, qv + 4 * s2)]           // X[j][j][k][c]
-                                                    : sB[gpcc_bi(mm, j) + gpcc_be(qv + 4 * s2, lrv)];         // X[mm][j][k][c]
-                        if (s2 & 1) S1 = PD::mfma(av, bv, S1);
-                        else S = PD::mfma(av, bv, S);
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) S[r] += S1[r];
-                d4 Y = {0.0, 0.0, 0.0, 0.0}, Y1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double dv = -sB[gpcc_bi(i, i) + gpcc_be(qv + 4 * r, lrv)];
-                    if (r & 1) Y1 = PD::mfma(dv, S[r], Y1);
-                    else Y = PD::mfma(dv, S[r], Y);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xo[n][r] = Y[r] + Y1[r];
-                xj[n] = j;
-            }
-        }
-        __syncthreads();   // every reader of L's row jb-1 is done
-        GPCC_OPAQUE_LANE(lrv, qv);
-        if (jb > 0) {
-            const int i = jb - 1;
-            if (store_l) {   // dense factor export only: L's row i leaves before inv(L)'s row i replaces it
-                for (int e = tid; e < i * 256; e += NT) {
-                    const int jj = e >> 8, rr = (e >> 4) & 15, cc = e & 15;
-                    Tt[gpcc_elem_off<T>(i * 16 + rr, jj * 16 + cc)] = (T)sB[gpcc_bi(i, jj) + gpcc_be(rr, cc)];
-                }
-                __syncthreads();
-            }
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-                if (xj[n] >= 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sB[gpcc_bi(i, xj[n]) + gpcc_be(qv + 4 * r, lrv)] = xo[n][r];   // X[i][j], untransposed
-                }
-        }
-        if (jb == 8) break;
-        GPCC_OPAQUE_LANE(lrv, qv);
-        // ---- (B) panel of column block jb: P = A[rf, jb] inv(D_jb)^T for the row fragments below, in place
-        for (int rf = jb + 1 + wave; rf < 8; rf += NT / 64) {
-            double av[4], bv[4];
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                av[s2] = sB[gpcc_bi(rf, jb) + gpcc_be(lrv, qv + 4 * s2)];
-                bv[s2] = sB[gpcc_bi(jb, jb) + gpcc_be(qv + 4 * s2, lrv)];   // B[k][c] = inv(D)[c][k]
-            }
-            d4 x = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) x = PD::mfma(av[s2], bv[s2], x);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sB[gpcc_bi(rf, jb) + gpcc_be(qv + 4 * r, lrv)] = x[r];
-        }
-        __syncthreads();
-    }
-    // sz now holds W_k
-    for (int e = tid; e < nrhs * GPCC_TILE; e += NT)
-        c.w[((long)slot * nrhs + e / GPCC_TILE) * c.Np + k * GPCC_TILE + (e % GPCC_TILE)] = sz[e];
-    for (int e = wave; e < nrhs * nrhs; e += NT / 64) {
-        const int ga = e / nrhs, gb = e % nrhs;
-        double pr = sz[ga * GPCC_TILE + lane] * sz[gb * GPCC_TILE + lane] +
-                    sz[ga * GPCC_TILE + 64 + lane] * sz[gb * GPCC_TILE + 64 + lane];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) pr += __shfl_xor(pr, o);
-        if (lane == 0) {
-            double *gp = c.gram + (long)slot * GPCC_MAXRHS * GPCC_MAXRHS + e;
-            pr += *gp;
-            *gp = pr;
-            sG[e] = pr;
-        }
-    }
-    if (wave == 3) {
-        double pr = 0.0;
-        if (lane < 8) pr = -(log(sr[96 + lane]) + sr[104 + lane] * 0.69314718055994530942);
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) pr += __shfl_xor(pr, o);
-        if (lane == 0) *sld = pr;
-    }
-    __syncthreads();
-    if (c.share_p && k == c.share_p - 1) {
-        const double ldp = *sld + c.logdet[slot];
-        double cs = 0.0, cm = 0.0;
-        if (track) {
-            cs = c.cond[2 * (long)slot];
-            cm = c.cond[2 * (long)slot + 1];
-            for (int b = 0; b < 8; ++b) {
-                cs += sr[112 + b];
-                cm = fmax(cm, sr[120 + b]);
-            }
-        }
-        for (int f = 1 + tid; f < g.cnt; f += NT) {
-            c.logdet[g.slot0 + f] = ldp;
-            if (track) {
-                c.cond[2 * (long)(g.slot0 + f)] = cs;
-                c.cond[2 * (long)(g.slot0 + f) + 1] = cm;
-            }
-            for (int i = 0; i < nrhs * nrhs; ++i) c.gram[(long)(g.slot0 + f) * GPCC_MAXRHS * GPCC_MAXRHS + i] = sG[i];
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        const double ld = *sld + c.logdet[slot];
-        c.logdet[slot] = ld;
-        if (track) {
-            double cs = c.cond[2 * (long)slot], cm = c.cond[2 * (long)slot + 1];
-            for (int b = 0; b < 8; ++b) {
-                cs += sr[112 + b];
-                cm = fmax(cm, sr[120 + b]);
-            }
-            c.cond[2 * (long)slot] = cs;
-            c.cond[2 * (long)slot + 1] = cm;
-            if (last && g.out_cond) {
-                g.out_cond[2 * (long)(g.first + m)] = cs;
-                g.out_cond[2 * (long)(g.first + m) + 1] = cm;
-            }
-        }
-        int bad = *sbad;
-        if (bad) c.info[slot] = k * GPCC_TILE + bad;
-        if (last) {
-            const double llv = gpcc_loglik_from_gram(c, sG, nrhs, ld, bad);
-            g.out_loglik[g.first + m] = bad ? __builtin_nan("") : llv;
-            g.out_info[g.first + m] = bad ? ((bad > c.N) ? bad : k * GPCC_TILE + bad) : 0;
-        }
-    }
-    // ---- write inv(L_kk) (operand of the panel solve) in tile layout; with store_l the zeros above L_kk's diagonal blocks too
-    T *Linv = (T *)c.linv + gpcc_linv_off(c, slot, k);
-#pragma unroll 2
-    for (int p0 = tid; p0 < NPIECE; p0 += NT) {
-        const int e = p0 * P::EP;
-        const int ch = e / (GPCC_TILE * P::KC), rem = e % (GPCC_TILE * P::KC), r = rem / P::KC, ks = rem % P::KC;
-        const int col0 = ch * P::KC + ((ks / P::EP) ^ gpcc_sw(r)) * P::EP;
-        const int rb = r >> 4, cb = col0 >> 4;
-        typename P::v16 xv;
-#pragma unroll
-        for (int h = 0; h < P::EP; ++h) {
-            const int col = col0 + h;
-            const int cbb = (cb < rb) ? cb : rb;   // (blocks above the diagonal: any valid address, masked below)
-            const int off = (cb < rb) ? gpcc_be(r & 15, col & 15) : gpcc_be(col & 15, r & 15);   // diagonal blocks hold inv(D)^T
-            const double x = sB[gpcc_bi(rb, cbb) + off];
-            xv[h] = (T)((col <= r) ? x : 0.0);
-        }
-        *(typename P::v16 *)(Linv + e) = xv;
-        if (store_l && cb > rb) {
-            typename P::v16 zv;
-#pragma unroll
-            for (int h = 0; h < P::EP; ++h) zv[h] = (T)0.0;
-            *(typename P::v16 *)(Tt + e) = zv;
-        }
-    }
-}
-
-// gpcc_diag_factor2: gpcc_diag_factor on the block image (half a CU's LDS)
-template <typename T>
-__global__ __launch_bounds__(GPCC_DIAG_THREADS, 4) void gpcc_diag_factor2(GpccCtx c, GpccGroup g, int k)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    gpcc_diag_blocks<T, false>(c, g, k, blockIdx.x, smem);
-}
-
-// the lower triangle of diagonal tile (k,k) minus its sum over the finished columns (nch chunks of tile row k), result in the
-// block image: the eight wave-specialised instances of gpcc_syrk_lower_wave
-template <typename T>
-__device__ __forceinline__ void gpcc_syrk_lower_blocks(const T *gRow, int nch, T *smem, const T *Tt, double *smem_d, int wave, int lane)
-{
-    switch (__builtin_amdgcn_readfirstlane(wave)) {
-    case 0: gpcc_syrk_lower_wave<T, 7, 0, 5, 0, 0, 0, true>(gRow, nch, smem, Tt, smem_d, wave, lane); break;
-    case 1: gpcc_syrk_lower_wave<T, 6, 0, 5, 0, 0, 0, true>(gRow, nch, smem, Tt, smem_d, wave, lane); break;
-    case 2: gpcc_syrk_lower_wave<T, 5, 0, 5, 0, 0, 0, true>(gRow, nch, smem, Tt, smem_d, wave, lane); break;
-    case 3: gpcc_syrk_lower_wave<T, 4, 0, 5, 0, 0, 0, true>(gRow, nch, smem, Tt, smem_d, wave, lane); break;
-    case 4: gpcc_syrk_lower_wave<T, 7, 5, 3, 0, 0, 1, true>(gRow, nch, smem, Tt, smem_d, wave, lane); break;
-    case 5: gpcc_syrk_lower_wave<T, 6, 5, 2, 1, 0, 2, true>(gRow, nch, smem, Tt, smem_d, wave, lane); break;
-    case 6: gpcc_syrk_lower_wave<T, 5, 5, 1, 2, 0, 3, true>(gRow, nch, smem, Tt, smem_d, wave, lane); break;
-    default: gpcc_syrk_lower_wave<T, 3, 0, 4, 0, 0, 0, true>(gRow, nch, smem, Tt, smem_d, wave, lane); break;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// gpcc_step (step k = -1 .. nt-2 of a left-looking group): ONE launch per step, the diagonal step of column k+1 UNDER the
-// update of column k (LAPACK's look-ahead, reached from cholesky(K), marginaliseb.jl:139).  gpcc_syrk_diag(k+1) depends on
-// one tile of step k only -- L(k+1,k) -- so the workgroup that owns that tile (the LOOK-AHEAD job, one per evaluation,
-// blockIdx < 8 ceil(cnt / 8): dispatched first) goes straight on:
-//     (1) update + solve of tile (k+1,k)                      [gpcc_update_solve_job, as every other job of the launch]
-//     (2) T'(k+1,k+1) = T(k+1,k+1) - sum_{j<=k} L(k+1,j) L(k+1,j)^T, lower triangle, tile row k+1 re-streamed (its last tile
-//         was written by this workgroup: visible behind the barrier)                                    [gpcc_syrk_lower_wave]
-//     (3) the diagonal step of column k+1: inv(L_{k+1,k+1}), W_{k+1}, sum log L_ii, W'W, info; on the last step the
-//         log-likelihood                                                                                [gpcc_diag_blocks]
-// while the other workgroups take the tiles (I,k), I >= k+2.  Everything a job reads from other workgroups was written by the
-// PREVIOUS launch (inv(L_kk), W_k, tile rows), so there is no hand-off inside a launch.  Launch k = -1 is the diagonal step of
-// column 0 alone; launch nt-2 holds only look-ahead jobs.  The two launches per step of gpcc_syrk_diag + gpcc_update_solve
-// become one, the diagonal chain (one workgroup per CU at MFMA-busy 0.65, 6.6 % of the N = 4096 sweep) runs beside update
-// workgroups of the same launch instead of alone on the chip, and every kernel of the step fits two workgroups per CU.
-// Same arithmetic as the two-launch path: bitwise identical results.
-// grid 8 ceil(cnt / 8) (nt - k - 1) (k = -1: 8 ceil(cnt / 8)), block 512, LDS GPCC_UPSOLVE_LDS_BYTES.
-// ------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(512, 4) void gpcc_step(GpccCtx c, GpccGroup g, int k)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int cnt8 = g.spread ? g.cnt : 8 * ((g.cnt + 7) / 8);   // (spread: fewer than 8 evaluations, every evaluation's jobs on all XCDs)
-    const int b = blockIdx.x;
-    if (b >= cnt8) {   // tile (I,k), I >= k+2
-        const int per = c.nt - k - 2, bb = b - cnt8;
-        const int x = bb & 7, qq = bb >> 3;
-        const int m = g.spread ? bb % g.cnt : (qq / per) * 8 + x;
-        if (m >= g.cnt) return;
-        const int slot = g.slot0 + m;
-        if (c.info[slot] != 0) return;
-        gpcc_update_solve_job<T, true>(c, k, k + 2 + (g.spread ? bb / g.cnt : qq % per), slot, (T *)smem_raw);
-        return;
-    }
-    const int m = b;
-    if (m >= g.cnt) return;
-    const int slot = g.slot0 + m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (c.info[slot] == 0) {
-        if (k >= 0) {
-            gpcc_update_solve_job<T, true>(c, k, k + 1, slot, (T *)smem_raw);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();   // tile (k+1,k) and z_{k+1} as this workgroup wrote them are visible to all its waves
-        }
-        const T *tiles = (const T *)c.tiles + (long)slot * c.slot_stride;
-        gpcc_syrk_lower_blocks<T>(tiles + gpcc_tile_off(k + 1, 0), GpccPrec<T>::NCH * (k + 1), (T *)smem_raw, tiles + gpcc_tile_off(k + 1, k + 1),
-                                  (double *)smem_raw, wave, lane);
-    }
-    gpcc_diag_blocks<T, true>(c, g, k + 1, m, (double *)smem_raw);   // (a failed evaluation is reported there)
 }
 
 // ------------------------------------------------------------------------------------------

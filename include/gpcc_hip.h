@@ -47,6 +47,11 @@ enum {
 
 int gpcc_version(void);
 
+/* What this library was built from: "src=<first 16 hex digits of the SHA-256 of its sources> defines=[<extra compiler defines>]".
+ * The product library is always built without extra defines (gpcc.jl_amd/build.py refuses them for the default output path); A/B
+ * libraries of tools/ carry theirs here.  bench.py prints it and quotes committed counter summaries only when it matches. */
+const char *gpcc_build_info(void);
+
 /* Last error text of a handle; handle == NULL gives the calling thread's last
  * handle-less error (gpcc_create / gpcc_covariance / gpcc_probabilities). */
 const char *gpcc_last_error(gpcc_handle_t handle);
@@ -86,53 +91,51 @@ int gpcc_multi_gathered(gpcc_handle_t handle, int which, long *blk_out, double *
  * call.  Any pointer may be NULL.  (One persistent host thread per device runs the shares; none is created per batch.) */
 int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms, double *total_ms);
 
-/* Tunables: "streams" (groups in flight on separate HIP streams, default 2 since round 3), "slots_per_stream"
- * (evaluations resident per group, default 256 = one diagonal-block workgroup per CU, capped so
- * the workspace stays under 64 GiB), "right_looking_max" (groups of at most this many evaluations use
- * the right-looking update, default 12), "fused_small_max" (groups of at most this many evaluations, default 12, run the
- * trailing update of a step and the next diagonal step in ONE launch: the latency path of a single objective(alpha, rho)),
- * "fused_solve" (1 = default: left-looking groups run the panel solve inside the update kernel and the diagonal tile's update
- * inside the diagonal step -- two launches per step; 0 = the three-kernel path of round 1; results agree to ~1e-13),
- * "fused_solve_min" (default 112: groups smaller than this keep the three-kernel path, which is faster there),
- * "fused_solve_min_split" (round 4, default 64: the same threshold for each half of a group that runs as two halves on two streams;
- * setting "fused_solve_min" below 64 or above 112 moves this one with it),
- * "step_fused" (round 4; 0 = default; 1: those two launches are ONE -- gpcc_step: the workgroup that owns tile (k+1,k) goes on into the
- * diagonal step of column k+1 while the rest of the launch updates column k, LAPACK's look-ahead; results bitwise those of
- * step_fused = 0), "diag_blocks" (round 4; 0 = default; 1: the diagonal step of the three-kernel path keeps the tile as 36 packed
- * 16 x 16 blocks and inverts in place -- 80 KiB of LDS instead of a whole CU's 158.7 KiB, bitwise the same results; both need at
- * most 4 right-hand sides, i.e. fp32 handles with more than 3 bands keep the round-2 kernels).  Both were built to let the
- * diagonal step run beside update workgroups and MEASURED not to pay (the fp64 matrix pipe bounds the step, and the pivot chain
- * runs 2-3x slower beside MFMA-saturating waves than alone on a CU: DESIGN.md 4.2e), hence off,
- * "look_ahead" (round 4; 0 = default; 1: the right-looking steps of groups of 13-111 evaluations issue the trailing update as "column
- * k + 1 first, then the rest" and run the diagonal step and panel solve of column k + 1 beside the rest, which goes to a low-priority
- * helper stream -- LAPACK's look-ahead where the chain's few workgroups find CUs of their own; bitwise the results of 0.  Measured: the
- * overlap works, the extra launch of single-tile jobs costs what it saves: +1 % for 13-20 evaluations, -2 ... -5 % for 24-64; off),
- * "fold_assembly" (round 4; 1 = default: groups of more than fused_small_max evaluations do not write the off-diagonal tiles of
- * delayedCovariance -- the job of the factorisation that reads a tile first evaluates its elements into its accumulators instead, the
- * same bits gpcc_model_matrix returns (all four kernels, fp64 and fp32 handles; the diagonal tiles, and tile column 0 on the
- * three-kernel path, are still assembled); 0 = every tile is assembled first, as in rounds 1-3),
- * "shared_prefix" (0 off; 1 = default: gpcc_loglik_batch detects a
- * batch whose evaluations all have the same band-1 amplitude, delay and rho -- a fixed-hyper-parameter delay
- * sweep, README.md:172-174 -- and then factorises the tile rows wholly inside band 1 once per group instead of
- * once per evaluation, results bitwise identical; 2 = the caller asserts that property, also for the _device
- * form).  Round 3: "small_n" (1 = default: N <= 383 -- the sizes of the reference's documentation, README.md:156-287, and a bit
- * beyond -- runs the small-N family: ONE launch per batch, one wave (N <= 191) or four waves per evaluation, the matrix in registers,
- * always fp64: the precision of an fp32 handle is IGNORED for N <= 383 (faster and more accurate there); 0 = the tile kernels; environment GPCC_SMALL_N sets the default), "hybrid_tail" (1 = default: left-looking groups of
- * 13-111 evaluations finish right-looking once their trailing matrices fit "hybrid_mall_mb" = 400 MB), "fit_device_unpack" /
- * "fit_speculate" / "fit_threads" (gpcc_grid_loglik on the small-N path: the kernel unpacks the optimiser's vectors itself;
- * latency-bound rounds evaluate all four candidate points of an iteration at once; large grids run as up to 4 slices on host
- * threads, 0 = by size -- none of the three changes a bit of the result).  "right_looking_max" now defaults to 12.
- * "split_min" / "split_max" / "split_nt_min" (24 / 240 (round 3: 160) / 12): a group of split_min ... split_max evaluations at N > 128 (split_nt_min - 1)
- * runs as two halves on two streams (the update of one half hides the diagonal-step / panel-solve chain of the other); split_min = 0:
- * never.  "split_small" (1): also 13-23 evaluations up to N = 2048 (13-19 up to N = 3072) and 6-12 evaluations from N = 2945 on, where that was measured to pay.
- * Diagnostic options (A/B measurements; defaults are the measured best): "hybrid_occ" (384: only steps with fewer left-looking jobs
- * than this become right-looking), "small_wide_max" (512: batches of at most this many evaluations run four waves per evaluation
- * on the small-N path), "trsm_rows_jobs" (0: three-kernel steps with at most this many panel-solve jobs use quarter-tile jobs),
- * "update_t" (0: the three-kernel path with the fused kernel's transposed main loop as its update).
- * gpcc_get_option also answers "N", "Np", "precision", "bytes_per_slot", "share_tiles", "n_devices", "gather_mode",
- * "small_n_max" (383), "small_n_active", "small_n_count", "gather_width", "workspace_streams" / "workspace_slots" (what the workspace
- * really holds: smaller than "streams" / "slots_per_stream" only if the device's memory was short when it was allocated -- then
- * gpcc_last_error carries a note; the options themselves are never rewritten). */
+/* Options (gpcc_set_option / gpcc_get_option).  Defaults are the measured best; none changes WHAT is computed, several select the
+ * factorisation path by group size (results of different paths agree to ~1e-13 relative in fp64).  History of every option, and of the
+ * variants that were measured and removed, is in LOG.md.
+ *
+ *   key                      default  meaning
+ *   -----------------------  -------  ---------------------------------------------------------------------------------------------
+ *   streams                  2        groups of a batch alternate between this many HIP streams
+ *   slots_per_stream         256      evaluations resident per group (fewer where 256 slots exceed 55 % of the device's memory)
+ *   chain_max                12       groups of at most this many evaluations at N >= 384 -- a single objective(alpha, rho),
+ *                                     marginaliseb.jl:133-141 called from Optim's loop, :209-211 -- run as ONE persistent launch
+ *                                     (gpcc_chain: two chain workgroups per evaluation carry diagonal step -> column solve -> next
+ *                                     diagonal tile without leaving their CUs, all other CUs pull trailing-update jobs; fp64 handles);
+ *                                     0 = the two-launches-per-step path below
+ *   fused_small_max          12       ... otherwise such groups run gpcc_panel_trsm_rows + gpcc_small_step (2 launches per step)
+ *   right_looking_max        12       groups of at most this many evaluations factorise right-looking
+ *   fused_solve              1        larger groups: panel solve inside the update kernel (gpcc_syrk_diag + gpcc_update_solve);
+ *                                     0 = the three-kernel path (gpcc_panel_update, gpcc_diag_factor, gpcc_panel_trsm) everywhere
+ *   fused_solve_min          112      ... from this group size on (smaller left-looking groups keep the three-kernel path)
+ *   fused_solve_min_split    64       ... the same threshold for each half of a split group (follows fused_solve_min when that is
+ *                                     set below 64 or above 112)
+ *   fold_assembly            1        groups of more than fused_small_max evaluations do not write the off-diagonal tiles of
+ *                                     delayedCovariance: the job that reads a tile first evaluates its elements (same bits)
+ *   hybrid_tail              1        three-kernel groups finish right-looking once their trailing matrices fit hybrid_mall_mb
+ *   hybrid_mall_mb           400      ... that budget (MB; the Infinity Cache is 256 MiB)
+ *   hybrid_occ               384      ... and only steps with fewer left-looking jobs than this become right-looking
+ *   split_min / split_max    24 / 240 a group of split_min .. split_max evaluations runs as two halves on two streams (0 = never)
+ *   split_nt_min             12       ... at N > 128 (split_nt_min - 1)
+ *   split_small              1        ... and the smaller groups for which that was measured to pay
+ *   shared_prefix            1        0 off; 1: gpcc_loglik_batch detects a fixed-hyper-parameter delay sweep (README.md:172-174) and
+ *                                     factorises the tile rows inside band 1 once per group (bitwise the same); 2: the caller asserts it
+ *   small_n                  1        N <= 383 runs the small-N family (one launch per batch, the matrix in registers, always fp64:
+ *                                     an fp32 handle's precision is ignored there); 0 = the tile kernels; env GPCC_SMALL_N = default
+ *   small_wide_max           512      small-N batches of at most this many evaluations run four waves per evaluation
+ *   fit_device_unpack        1        gpcc_grid_loglik, small-N path: the kernel unpacks the optimiser's vectors itself
+ *   fit_speculate            1        ... latency-bound rounds evaluate all four candidate points of an iteration at once
+ *   fit_threads              0        ... host threads (slices) of a large fit; 0 = by size
+ *   fp32_refine              1        fp32 handles: fp64 refinement of the quadratic forms
+ *   fp32_guard               1        fp32 handles: evaluations whose pivot ratios exceed the limits are repeated in fp64
+ *   fp32_assemble            1        fp32 handles: tiles inside one band pair are evaluated in fp32
+ *
+ * Read-only keys of gpcc_get_option: "N", "Np", "precision", "bytes_per_slot", "share_tiles", "n_devices", "gather_mode",
+ * "gather_width", "small_n_max" (383), "small_n_active", "small_n_count", "chain_count" (evaluations that took the persistent
+ * launch so far), "fp32_guard_count", "workspace_streams" / "workspace_slots" (what the workspace really holds: smaller than "streams" /
+ * "slots_per_stream" only if the device's memory was short when it was allocated -- then gpcc_last_error carries a note; the
+ * options themselves are never rewritten). */
 int gpcc_set_option(gpcc_handle_t handle, const char *key, long value);
 long gpcc_get_option(gpcc_handle_t handle, const char *key);
 
@@ -270,6 +273,13 @@ int gpcc_profile_get(gpcc_handle_t handle, int which, long *launches, double *to
 
 /* On-device self-test of the f64 MFMA fragment maps and a timing probe of the fp64 MFMA rate:
  * returns 0 when the maps are as the kernels assume; *tflops (may be NULL) = measured rate. */
+/* Measurement plumbing of the persistent few-evaluation launch (option "chain_max"): with option "chain_trace" = 1 its chain
+ * workgroups stamp the device's wall clock per diagonal step k; out_us[4 k + 0 / 1 / 2] = microseconds (from the first stamp of the
+ * evaluation) at which the workgroup of step k began to build tile (k,k), had it complete (first pivot next), had published the whole
+ * step; -1 where nothing was stamped.  `evaluation` = index in the last group of at most chain_max evaluations; capacity >= 4 nt
+ * doubles (nt = Np / 128).  tools/chain_trace.py prints the critical chain from it. */
+int gpcc_chain_trace(gpcc_handle_t handle, int evaluation, double *out_us, int capacity);
+
 int gpcc_selftest(int device_id, double *mfma_f64_tflops);
 
 #ifdef __cplusplus

@@ -1,0 +1,166 @@
+"""The persistent few-evaluation launch (csrc/gpcc_chain.hip.h: groups of at most `chain_max` evaluations on an fp64 handle at
+N > 128 -- call site 1 of the boundary, one objective(alpha, rho), marginaliseb.jl:133-141) against the golden fixtures, the CPU
+oracle, and the launch-per-step path it replaces (chain_max = 0), through the C ABI.
+
+Tolerances: 1e-8 relative against golden / oracle (the north-star bar is 1e-6), 1e-11 against the launch-per-step path (the same
+tile algorithm in another summation order)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LL_RTOL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def gp():
+    import torch
+    torch.cuda.init()
+    import gpcc_amd
+    return gpcc_amd
+
+
+def _rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b)) / np.abs(np.asarray(b)))
+
+
+def test_chain_golden_cases(gp, golden, monkeypatch):
+    """The 44 golden log-likelihoods on the tile kernels (GPCC_SMALL_N=0), one evaluation per call: those with N > 128 take the
+    persistent launch (two tiles), the others the one-tile path -- both must give the golden value."""
+    monkeypatch.setenv("GPCC_SMALL_N", "0")
+    worst, took = 0.0, 0
+    for c in golden["cases"]:
+        with gp.Objective(c["t"], c["y"], c["sigma"], c["kernel"], marginalise_b=c["marginalise_b"], slots_per_stream=4) as obj:
+            ll, info = obj.loglik_batch([c["delays"]], [c["alpha"]], [c["rho"]])
+            took += obj.get_option("chain_count")
+        assert info[0] == 0
+        worst = max(worst, abs(ll[0] - c["loglik"]) / abs(c["loglik"]))
+    print("worst relative error vs golden: %.3e; %d of %d cases took the persistent launch" % (worst, took, len(golden["cases"])))
+    assert worst <= LL_RTOL
+    assert took > 0
+
+
+@pytest.mark.parametrize("Nl,kname,mb", [([257, 256], "matern32", True), ([512, 512], "OU", True), ([512, 512], "rbf", False),
+                                         ([2048, 2048], "matern32", True), ([1365, 1365, 1365], "matern52", True)])
+def test_chain_vs_oracle_and_launch_per_step_path(gp, oracle, Nl, kname, mb):
+    """N = 513 (ragged last tile), 1024, 4096, 4095 (three bands): M = 1, 2, 5, 12 evaluations per call with different (tau, alpha,
+    rho) -- against the oracle, against the same handle with chain_max = 0, bitwise repeatable, chain_count says the path ran."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves(Nl, seed=3, gap_band=1)
+    L = len(Nl)
+    rng = np.random.default_rng(11)
+    M = 12
+    delays = np.concatenate([np.zeros((M, 1)), rng.random((M, L - 1)) * 10], 1)
+    alpha = 0.5 + rng.random((M, L)) * 2
+    rho = 1.0 + rng.random(M) * 5
+    nref = 12 if sum(Nl) <= 1100 else 3
+    ref, rinfo = oracle.loglik_batch(kname, t, y, s, delays[:nref], alpha[:nref], rho[:nref], mb, nthreads=8)
+    assert (rinfo == 0).all()
+    with gp.Objective(t, y, s, kname, marginalise_b=mb, slots_per_stream=16) as obj:
+        assert obj.get_option("chain_max") == 12
+        out = {}
+        for m in (1, 2, 5, 12):
+            before = obj.get_option("chain_count")
+            ll, info = obj.loglik_batch(delays[:m], alpha[:m], rho[:m])
+            assert obj.get_option("chain_count") == before + m, "the group did not take the persistent launch"
+            assert (info == 0).all()
+            out[m] = ll
+            ll2, _ = obj.loglik_batch(delays[:m], alpha[:m], rho[:m])
+            assert np.array_equal(ll, ll2), "not repeatable"
+        # an evaluation does not depend on the group it travels in
+        for m in (1, 2, 5):
+            assert np.array_equal(out[m], out[12][:m])
+        assert _rel(out[12][:nref], ref) <= LL_RTOL
+        # the closure form: one objective(alpha, rho)
+        assert obj(alpha[0], rho[0], delays[0]) == out[12][0]
+        obj.set_option("chain_max", 0)
+        before = obj.get_option("chain_count")
+        ll_old, info_old = obj.loglik_batch(delays, alpha, rho)
+        assert obj.get_option("chain_count") == before and (info_old == 0).all()
+        print("N = %d %s: chain vs oracle %.2e, vs launch-per-step path %.2e" % (sum(Nl), kname, _rel(out[12][:nref], ref), _rel(out[12], ll_old)))
+        assert _rel(out[12], ll_old) <= 1e-11
+
+
+def test_chain_status_codes(gp):
+    """A non-positive pivot in the FIRST, a middle and the last tile, argument errors, and valid evaluations in the same group: info as
+    the launch-per-step path reports it (LAPACK-style: the order of the first non-positive pivot), NaN log-likelihood.  The singular
+    pair: two observations at the same time, far from all others (the OU kernel underflows to exactly 0 towards them), unit amplitude,
+    sigma = 0, no B term -- their 2 x 2 block is [[1, 1], [1, 1]] whatever was eliminated before, the second pivot exactly 0."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([300, 340], seed=4)
+    rho = 3.5
+    for dup in (5, 300 + 20, 300 + 339):     # the second copy sits in tile 0, tile 2, the last tile (N = 640: 5 tiles)
+        t2 = [t[0].copy(), t[1].copy()]
+        s2 = [np.full(300, 0.5), np.full(340, 0.5)]
+        b, i = (0, dup) if dup < 300 else (1, dup - 300)
+        t2[b][i] = t2[b][i - 1] = 1.0e6
+        s2[b][i] = s2[b][i - 1] = 0.0
+        with gp.Objective(t2, y, s2, "OU", marginalise_b=False, slots_per_stream=8) as obj:
+            d = [[0.0, 0.0]] * 4
+            a = [[1.0, 1.0], [1.0, -1.0], [1.0, 1.0], [1.0, 1.0]]
+            r = [rho, 1.0, 0.0, rho]
+            ll, info = obj.loglik_batch(d, a, r)
+            assert obj.get_option("chain_count") == 4
+            obj.set_option("chain_max", 0)
+            ll0, info0 = obj.loglik_batch(d, a, r)
+        print("second copy at %d: info %s (launch-per-step path: %s)" % (dup, info, info0))
+        assert info[1] == -1 and info[2] == -2 and np.isnan(ll[1]) and np.isnan(ll[2])
+        assert info[0] == info[3] == dup + 1 and np.isnan(ll[0]) and np.isnan(ll[3])
+        assert np.array_equal(info, info0)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    # valid and invalid evaluations side by side
+    with gp.Objective(t, y, s, "matern32", slots_per_stream=8) as obj:
+        ll, info = obj.loglik_batch([[0.0, 1.0], [0.0, 2.0], [0.0, 3.0]], [list(alpha), [0.0, 1.0], list(alpha)], [rho, rho, rho])
+        assert info[0] == 0 and info[1] == -1 and info[2] == 0 and np.isnan(ll[1])
+        ok, _ = obj.loglik_batch([[0.0, 1.0], [0.0, 3.0]], [list(alpha)] * 2, [rho, rho])
+        assert np.array_equal(ok, ll[[0, 2]])
+        with pytest.raises(AssertionError):
+            obj([0.0, 1.0], rho, [0.0, 1.0])
+        with pytest.raises(ValueError):
+            obj(alpha, -1.0, [0.0, 1.0])
+
+
+def test_chain_is_fp64_only_and_other_paths_unchanged(gp, oracle):
+    """fp32 handles, groups above chain_max and the dense utilities keep their paths (chain_count stays 0) and their results."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([400, 400], seed=6)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    d = np.stack([np.zeros(3), np.array([0.5, 1.5, 2.5])], 1)
+    ref, _ = oracle.loglik_batch("matern32", t, y, s, d, np.tile(alpha, (3, 1)), np.full(3, rho), True, nthreads=4)
+    with gp.Objective(t, y, s, "matern32", precision="fp32") as obj:
+        ll, info = obj.loglik_batch(d, np.tile(alpha, (3, 1)), np.full(3, rho))
+        assert obj.get_option("chain_count") == 0 and (info == 0).all() and _rel(ll, ref) <= 1e-3
+    with gp.Objective(t, y, s, "matern32", slots_per_stream=32) as obj:
+        M = 13
+        dd = np.stack([np.zeros(M), np.linspace(0, 6, M)], 1)
+        ll13, info = obj.loglik_batch(dd, np.tile(alpha, (M, 1)), np.full(M, rho))
+        assert obj.get_option("chain_count") == 0 and (info == 0).all()
+        ll12, _ = obj.loglik_batch(dd[:12], np.tile(alpha, (12, 1)), np.full(12, rho))
+        assert obj.get_option("chain_count") == 12
+        assert _rel(ll12, ll13[:12]) <= 1e-11
+        K = obj.model_matrix(d[0], alpha, rho)
+        assert np.array_equal(K, K.T)
+        Lf, finfo = obj.factor(d[0], alpha, rho)
+        assert finfo == 0 and obj.get_option("chain_count") == 12
+
+
+def test_chain_many_calls_and_two_streams(gp):
+    """A batch whose LAST group is small (the others are full groups on alternating streams) and 200 single calls in a row: the flag
+    words are re-zeroed per launch, nothing accumulates."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([320, 320], seed=8)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    with gp.Objective(t, y, s, "matern32", slots_per_stream=16, streams=2) as obj:
+        M = 16 * 3 + 5     # groups of 16, 16, 16 and 5: the last one takes the persistent launch
+        dd = np.stack([np.zeros(M), np.linspace(0, 9, M)], 1)
+        ll, info = obj.loglik_batch(dd, np.tile(alpha, (M, 1)), np.full(M, rho))
+        assert (info == 0).all() and obj.get_option("chain_count") == 5
+        obj.set_option("chain_max", 0)
+        ll0, _ = obj.loglik_batch(dd, np.tile(alpha, (M, 1)), np.full(M, rho))
+        assert _rel(ll, ll0) <= 1e-11
+        obj.set_option("chain_max", 12)
+        first = None
+        for _ in range(200):
+            v = obj(alpha, rho, [0.0, 2.0])
+            first = v if first is None else first
+            assert v == first

@@ -37,13 +37,11 @@ def _batch(Nl, y, M, seed, spread=12.0):
 
 FUSED = (("right_looking_max", 0), ("shared_prefix", 0), ("fused_solve_min", 1), ("split_min", 0))
 # the three-kernel path (fold = 2: the first gpcc_panel_update job that touches a tile evaluates it): left-looking with a right-looking
-# tail, right-looking from step 0 (also with the look-ahead's two-part update), the default dispatch of 40 (two halves on two streams)
+# tail, right-looking from step 0, the default dispatch of 40 (two halves on two streams)
 THREE = {"tail": (16, (("shared_prefix", 0), ("split_min", 0), ("split_small", 0))),
          "left": (16, (("shared_prefix", 0), ("split_min", 0), ("split_small", 0), ("hybrid_tail", 0))),
-         "right": (20, (("shared_prefix", 0), ("right_looking_max", 64), ("fused_small_max", 0), ("split_min", 0), ("split_small", 0))),
-         "right+la": (20, (("shared_prefix", 0), ("right_looking_max", 64), ("fused_small_max", 0), ("split_min", 0), ("split_small", 0),
-                           ("look_ahead", 1))),
-         "spread": (5, (("shared_prefix", 0), ("fused_small_max", 0), ("split_min", 0), ("split_small", 0))),
+         "right": (20, (("shared_prefix", 0), ("right_looking_max", 64), ("fused_small_max", 0), ("chain_max", 0), ("split_min", 0), ("split_small", 0))),
+         "spread": (5, (("shared_prefix", 0), ("fused_small_max", 0), ("chain_max", 0), ("split_min", 0), ("split_small", 0))),
          "default40": (40, (("shared_prefix", 0),))}
 
 

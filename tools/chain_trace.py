@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""What one evaluation's critical chain consists of inside the persistent launch (csrc/gpcc_chain.hip.h): per diagonal step k the
+device wall-clock stamps of the chain workgroup that runs it -- began to build tile (k,k) | image complete (first pivot next) | step
+published (xrow = 9) -- and what the table derives from them: the time the chain spent BETWEEN the end of step k - 1 and the first pivot
+of step k (the hand-off: last row block of inv(L) out -> last column block of L(k,k-1) solved and published -> folded into the tile),
+and the diagonal step itself.
+  python tools/chain_trace.py [--n-per-band 2048] [--bands 2] [--evals 1]"""
+import argparse
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import gpcc_amd  # noqa: E402
+from gpcc_amd import synthetic  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n-per-band", type=int, default=2048)
+ap.add_argument("--bands", type=int, default=2)
+ap.add_argument("--evals", type=int, default=1)
+ap.add_argument("--every", type=int, default=1, help="print every n-th step")
+args = ap.parse_args()
+t, y, s, _ = synthetic.simulate_lightcurves([args.n_per_band] * args.bands, seed=1)
+alpha, rho = synthetic.default_hyperparameters(y)
+M = args.evals
+d = np.concatenate([np.zeros((M, 1)), np.linspace(0, 20, M)[:, None] * np.ones((1, args.bands - 1))], 1)
+with gpcc_amd.Objective(t, y, s, "matern32", slots_per_stream=16) as obj:
+    obj.set_option("chain_trace", 1)
+    for _ in range(3):
+        ll, info = obj.loglik_batch(d, np.tile(alpha, (M, 1)), np.full(M, rho))
+    for m in range(M):
+        tr = obj.chain_trace(m)
+        nt = len(tr)
+        print("== N = %d, evaluation %d of %d in the group: %d diagonal steps, chain %.1f us from the first stamp to the last" % (
+            args.n_per_band * args.bands, m, M, nt, tr[:, 2].max()))
+        print("%4s %12s %12s %12s | %10s %10s %10s" % ("k", "build from", "image at", "published", "hand-off", "diag step", "wait+build"))
+        hand, diag = [], []
+        for k in range(nt):
+            prev_end = tr[k - 1, 2] if k else 0.0
+            h = tr[k, 1] - prev_end          # end of step k-1 -> first pivot of step k can start
+            dg = tr[k, 2] - tr[k, 1]
+            hand.append(h)
+            diag.append(dg)
+            if k % args.every == 0 or k == nt - 1:
+                print("%4d %12.2f %12.2f %12.2f | %10.2f %10.2f %10.2f" % (k, tr[k, 0], tr[k, 1], tr[k, 2], h, dg, tr[k, 1] - tr[k, 0]))
+        print("sum of hand-offs %.1f us (mean %.2f), sum of diagonal steps %.1f us (mean %.2f)" % (
+            sum(hand[1:]), np.mean(hand[1:]) if nt > 1 else 0.0, sum(diag), np.mean(diag)))
