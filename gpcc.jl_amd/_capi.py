@@ -67,6 +67,7 @@ SIGNATURES = {
     "gpcc_profile_reset": (ctypes.c_int, [ctypes.c_void_p]),
     "gpcc_profile_get": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_long_p, c_double_p]),
     "gpcc_chain_trace": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, ctypes.c_int]),
+    "gpcc_chain_jobs_trace": (ctypes.c_int, [ctypes.c_void_p, c_double_p, ctypes.c_long, c_long_p]),
     "gpcc_selftest": (ctypes.c_int, [ctypes.c_int, c_double_p]),
 }
 

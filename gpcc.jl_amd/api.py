@@ -234,11 +234,18 @@ class Objective:
         return comp, g.value, tot.value
 
     def chain_trace(self, evaluation=0):
-        """Stamps of the last persistent few-evaluation launch (option "chain_trace" = 1): (nt, 4) microseconds (gpcc_chain_trace)."""
+        """Stamps of the last persistent few-evaluation launch (option "chain_trace" = 1): (nt, 80) microseconds (gpcc_chain_trace)."""
         nt = self.get_option("Np") // 128
-        out = np.empty(4 * nt, dtype=np.float64)
+        out = np.empty(80 * nt, dtype=np.float64)
         self._chk(_capi.load().gpcc_chain_trace(self._h, int(evaluation), _dp(out), out.size))
-        return out.reshape(nt, 4)
+        return out.reshape(nt, 80)
+
+    def chain_jobs_trace(self, capacity=32768):
+        """The workers' jobs of the last persistent launch: (rows, 6) [kind, step, index, fetched, ready, done] (gpcc_chain_jobs_trace)."""
+        out = np.empty(6 * capacity, dtype=np.float64)
+        n = ctypes.c_long(0)
+        self._chk(_capi.load().gpcc_chain_jobs_trace(self._h, _dp(out), capacity, ctypes.byref(n)))
+        return out[:6 * n.value].reshape(n.value, 6)
 
     # -- the hot path ---------------------------------------------------------------------------
     def _params(self, delays, alpha, rho):

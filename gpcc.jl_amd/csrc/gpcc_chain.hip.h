@@ -38,13 +38,17 @@
 #include "gpcc_kernels.hip.h"
 
 #define GPCC_CHAIN_THREADS 512
-#define GPCC_CHAIN_LDS_BYTES (96 * 1024)   /* > 80 KiB on purpose: ONE workgroup per CU -- the pivot chain runs 2-3x slower beside MFMA waves */
+#define GPCC_CHAIN_LDS_BYTES (100 * 1024)  /* three 32 KiB operand stages + control words; > 80 KiB on purpose: ONE workgroup per CU -- the pivot chain runs 2-3x slower beside MFMA waves */
 #define GPCC_CHAIN_MAX_EVALS 16
 #define GPCC_CHAIN_SPIN_LIMIT (1u << 22)
 #define GPCC_CHAIN_MAXRHS 4
+#define GPCC_CHAIN_TLD 18
+#define GPCC_CHAIN_TMP_OFF (GPCC_XIMG_ELEMS + GPCC_CHAIN_MAXRHS * GPCC_TILE + GPCC_TILE + 2)   /* doubles: gpcc_chain_diag's stmp */
 #define GPCC_XIMG_ELEMS (36 * 256)         /* the lower 36 blocks of inv(L_kk), 16 x 16 row-major each */
 #define GPCC_INFO_TIMEOUT (-9)
 #define GPCC_CHAIN_STEPVALS (2 + GPCC_CHAIN_MAXRHS * GPCC_CHAIN_MAXRHS)
+#define GPCC_CHAIN_WTRACE_CAP 32768        /* job stamps kept per launch */
+#define GPCC_CHAIN_TRACE_WORDS 80          /* stamps per diagonal step: 3 of the role + 8 per block step */
 
 typedef unsigned gpcc_u4 __attribute__((ext_vector_type(4)));
 #ifndef GPCC_CHAIN_FN
@@ -56,7 +60,9 @@ struct GpccChainArgs {
                                  //   xrow[nt] | colflag[nt][8] | lcnt[ntiles] | ver[ntiles]
     double *ximg;                // evaluations x nt x GPCC_XIMG_ELEMS: inv(L_kk) as published (block (f, ch) at gpcc_bi(f, ch), [row][col] row-major)
     double *stepval;             // evaluations x nt x GPCC_CHAIN_STEPVALS: per diagonal step [sum log L_ii of the block, first bad pivot, W'W]
-    unsigned long long *trace;   // optional (NULL): evaluations x nt x 4 wall-clock stamps of the chain (tools/chain_trace.py)
+    unsigned long long *trace;   // optional (NULL): evaluations x nt x GPCC_CHAIN_TRACE_WORDS wall-clock stamps of the chain (tools/chain_trace.py)
+    unsigned long long *wtrace;  // optional (NULL): wtrace_cap x 4 stamps of the workers' jobs: [kind | step | tile, fetched, dependencies met, done]; words[1] counts
+    int wtrace_cap;
     int ev_words;                // words per evaluation
     int qbase;                   // first per-evaluation word
 };
@@ -176,6 +182,8 @@ GPCC_CHAIN_FN void gpcc_chain_diag(const GpccCtx &c, const GpccGroup &g, const G
     double *sz = sB + GPCC_XIMG_ELEMS;                   // nrhs x 128: Z_k, later W_k
     double *sr = sz + GPCC_CHAIN_MAXRHS * GPCC_TILE;     // [0, 80): wave 0's column scratch; [96, 112): per-block statistics
     int *sbad = (int *)(sr + GPCC_TILE);
+    double *stmp = sr + GPCC_TILE + 2;                   // 16 x GPCC_CHAIN_TLD: the diagonal block about to be factored, ROW-MAJOR (a lane reads its row
+                                                         // with eight 16-byte loads, conflict-free at this stride); block (0,0) arrives with the image
 
     const int lane = tid & 63, lr = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -186,16 +194,26 @@ GPCC_CHAIN_FN void gpcc_chain_diag(const GpccCtx &c, const GpccGroup &g, const G
     double *xk = a.ximg + ((long)m * c.nt + k) * GPCC_XIMG_ELEMS;
     const __amdgpu_buffer_rsrc_t xr = gpcc_rsrc(xk, GPCC_XIMG_ELEMS * 8);
 
-    for (int e = tid; e < nrhs * GPCC_TILE; e += NT)
-        sz[e] = gpcc_ld_sc1(c.z + ((long)slot * nrhs + e / GPCC_TILE) * c.Np + k * GPCC_TILE + (e % GPCC_TILE));
     if (tid == 0) *sbad = 0;
+    unsigned long long *trd = a.trace ? a.trace + ((long)m * c.nt + k) * GPCC_CHAIN_TRACE_WORDS + 8 : nullptr;   // [jb][8]: (A) begins, (A) done, behind the first barrier, behind the second; wave 0: fold done, block loaded, factored, stored
     __syncthreads();
     for (int jb = 0; jb <= 8; ++jb) {
+        if (trd && tid == 0) trd[8 * jb] = wall_clock64();
         const int r0 = jb * 16;
         int lrv = lr, qv = q;   // opaque per-phase copies: keeps the compiler from hoisting every lane-dependent address of all nine rounds out of the loop
         GPCC_OPAQUE_LANE(lrv, qv);
         d4 xo[2];            // rows of inv(L) built in this round: written after the barrier (in place of L's row)
         int xj[2] = {-1, -1};
+        if (wave == 4 && jb == 0) {
+            // z_k: the right-hand side of this step's forward substitution.  Its last update -- z_k -= L(k,k-1) w_{k-1} -- is the END of the
+            // four quarter solves of tile (k,k-1) (lcnt = 4), a hand-off later than the last column block this workgroup has just folded
+            // in; it is first read by the W task of block step 1, two barriers from here: loaded now, beside the first 16 pivots
+            bool okz = true;
+            if (k > 0 && lane == 0) okz = gpcc_wait_ge(&fl.lcnt[gpcc_tile_idx(k, k - 1)], 4u, fl.abortw, 0x210u);
+            (void)okz;   // (abandoned launch: the step finishes on stale data and the workgroup leaves at its next wait)
+            for (int e = lane; e < nrhs * GPCC_TILE; e += 64)
+                sz[e] = gpcc_ld_sc1(c.z + ((long)slot * nrhs + e / GPCC_TILE) * c.Np + k * GPCC_TILE + (e % GPCC_TILE));
+        }
         if (wave == 4 && jb >= 2) {   // row block jb - 2 of inv(L) is final: out it goes (nothing of it is written any more)
             for (int j = 0; j <= jb - 2; ++j) gpcc_chain_publish_block(sB, xr, jb - 2, j, lane);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -215,57 +233,37 @@ GPCC_CHAIN_FN void gpcc_chain_diag(const GpccCtx &c, const GpccGroup &g, const G
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) x = PD::mfma(pa[s2], pb[s2], x);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sB[gpcc_bi(jb, jb) + gpcc_be(qv + 4 * r, lrv)] = x[r];
+                for (int r = 0; r < 4; ++r) stmp[(qv + 4 * r) * GPCC_CHAIN_TLD + lrv] = x[r];   // (the image's block is overwritten by inv(L_D)^T below anyway)
             }
+            if (trd && tid == 0) trd[8 * jb + 4] = wall_clock64();
             if (jb < 8) {
                 // ---- (A) 16x16 potf2 + inverse in registers: lanes 0-15 own the rows of D, lanes 16-31 the columns of inv(L_D); ONE
-                // right-looking instruction stream for both: once column j of L is final, v[j] <- v[j] / sqrt(d_j) is L[l][j] on an L lane
-                // and X[j][l] on an X lane, and the same v[cc] -= v[j] L[cc][j] updates the trailing row and the running sums
+                // right-looking instruction stream for both (gpcc_potf2_core)
                 const bool xl = qv != 0;
                 double v[16];
                 double *blk = sB + gpcc_bi(jb, jb);
 #pragma unroll
-                for (int cc = 0; cc < 16; ++cc) v[cc] = xl ? ((cc == lrv) ? 1.0 : 0.0) : blk[gpcc_be(lrv, cc)];
-                int bad = 0;
-                double py = 1.0;   // prod of the mantissas of 1/sqrt(d_j) ...
-                int pe = 0;        // ... and the sum of their exponents: no overflow whatever the scale of K
-                // software-pipelined: the broadcast column of pivot j is fetched (cn) and applied to columns >= j+2 during the reciprocal
-                // square root of pivot j+1 -- only column j+1 (through v_readlane) is on the pivot-to-pivot chain
-                double cn[16];
-#pragma unroll
-                for (int cc = 0; cc < 16; ++cc) cn[cc] = 0.0;
-                double d = gpcc_bcast(v[0], 0), vp = 0.0;
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    if (!(d > 0.0) && bad == 0) bad = j + 1;
-                    const double y = gpcc_rsqrt(d);
-                    if (j >= 1) {   // the rest of pivot j-1's rank-1 update (column j had its share through the readlane below)
-#pragma unroll
-                        for (int cc = j + 1; cc < 16; ++cc) {
-                            v[cc] = __builtin_fma(-vp, cn[cc], v[cc]);
-                            asm volatile("" : "+v"(v[cc]));   // applied NOW (left alone the compiler sinks the updates to their readers
-                                                              // and keeps every broadcast column alive: > 256 VGPRs)
-                        }
-                    }
-                    py *= __builtin_amdgcn_frexp_mant(y);
-                    pe += __builtin_amdgcn_frexp_exp(y);
-                    v[j] *= y;
-                    if (j < 15) {
-                        sr[qv == 0 ? lrv : 16 + lane] = v[j];
-                        const double lnx = gpcc_bcast(v[j], j + 1);
-                        v[j + 1] = __builtin_fma(-v[j], lnx, v[j + 1]);
-                        d = gpcc_bcast(v[j + 1], j + 1);
-                        vp = v[j];
-#pragma unroll
-                        for (int cc = j + 2; cc < 16; ++cc) cn[cc] = sr[cc];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int h2 = 0; h2 < 8; ++h2) {
+                    const d2 rw = *(const d2 *)(stmp + lrv * GPCC_CHAIN_TLD + 2 * h2);
+                    v[2 * h2] = xl ? ((2 * h2 == lrv) ? 1.0 : 0.0) : rw[0];
+                    v[2 * h2 + 1] = xl ? ((2 * h2 + 1 == lrv) ? 1.0 : 0.0) : rw[1];
                 }
+                double py = 1.0;   // prod of 1/sqrt(d_j) as mantissa ...
+                int pe = 0;        // ... and exponent: no overflow whatever the scale of K
+                double rs_ = 0.0, rm_ = 0.0, quad_ = 0.0;
+                if (trd) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (tid == 0) trd[8 * jb + 5] = wall_clock64();
+                }
+                const int bad = gpcc_potf2_core<false, false>(v, sr, lrv, qv, lane, false, py, pe, quad_, sr, rs_, rm_);   // (gpcc_kernels.hip.h)
+                if (trd && tid == 0) trd[8 * jb + 6] = wall_clock64();
                 if (lane < 32) {
                     if (xl) {   // column lrv of X = inv(L_D) as row lrv of the block: the block now holds inv(L_D)^T
 #pragma unroll
-                        for (int cc = 0; cc < 16; ++cc) blk[gpcc_be(lrv, cc)] = v[cc];
+                        for (int h2 = 0; h2 < 8; ++h2) {   // (gpcc_be keeps the pairs (2 h, 2 h + 1) adjacent: 16-byte stores)
+                            const d2 pr2 = {v[2 * h2], v[2 * h2 + 1]};
+                            *(d2 *)(blk + gpcc_be(lrv, 2 * h2)) = pr2;
+                        }
                     }
                     if (lane == 0 && bad && *sbad == 0) *sbad = r0 + bad;
                     if (lane == 0) {
@@ -273,6 +271,7 @@ GPCC_CHAIN_FN void gpcc_chain_diag(const GpccCtx &c, const GpccGroup &g, const G
                         sr[104 + jb] = (double)pe;
                     }
                 }
+                if (trd && tid == 0) trd[8 * jb + 7] = wall_clock64();
             }
         } else if (wk >= 0 && jb > 0) {
             const int jp = jb - 1;
@@ -390,7 +389,9 @@ GPCC_CHAIN_FN void gpcc_chain_diag(const GpccCtx &c, const GpccGroup &g, const G
                 xj[n] = j;
             }
         }
+        if (trd && tid == 0) trd[8 * jb + 1] = wall_clock64();
         __syncthreads();   // every reader of L's row jb-1 is done
+        if (trd && tid == 0) trd[8 * jb + 2] = wall_clock64();
         GPCC_OPAQUE_LANE(lrv, qv);
         if (jb > 0) {
             const int i = jb - 1;
@@ -418,6 +419,7 @@ GPCC_CHAIN_FN void gpcc_chain_diag(const GpccCtx &c, const GpccGroup &g, const G
             for (int r = 0; r < 4; ++r) sB[gpcc_bi(rf, jb) + gpcc_be(qv + 4 * r, lrv)] = x[r];
         }
         __syncthreads();
+        if (trd && tid == 0) trd[8 * jb + 3] = wall_clock64();
     }
     __syncthreads();   // row block 7 of inv(L) is in the image, sz holds W_k
     // ---- the end of the step goes out together: row block 7 of inv(L) (one block per wave), W_k, the step's scalars -- then ONE flag
@@ -472,8 +474,8 @@ GPCC_CHAIN_FN void gpcc_chain_diag(const GpccCtx &c, const GpccGroup &g, const G
 // ------------------------------------------------------------------------------------------
 // The image of tile (k,k) for the chain: lower triangle of T(k,k) (every update of columns < k-1 applied by the workers) minus
 // L(k,k-1) L(k,k-1)^T, the column blocks of L(k,k-1) folded in AS THE FOUR QUARTER SOLVES PUBLISH THEM (colflag).  36 blocks in the
-// registers of eight waves, dealt 5/5/5/5/4/4/4/4 (gpcc_syrk_lower_wave's split); a column block is 16 KiB, loaded by all threads with
-// sc1 register loads into one LDS stage.  Returns false if abandoned.
+// registers of eight waves, dealt 5/5/5/5/4/4/4/4 (gpcc_syrk_lower_wave's split); a column block is 16 KiB, copied by LDS-DMA (sc1)
+// into one of two LDS stages.  Returns false if abandoned.
 // ------------------------------------------------------------------------------------------
 template <int RA, int CA, int NA, int RB, int CB, int NB>
 GPCC_CHAIN_FN bool gpcc_chain_syrk_wave(const double *Tt, const double *Lt, const unsigned *colflag, unsigned *abortw, double *smem, int *ctl,
@@ -488,33 +490,34 @@ GPCC_CHAIN_FN bool gpcc_chain_syrk_wave(const double *Tt, const double *Lt, cons
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[i][r] = -gpcc_ld_sc1(Tt + gpcc_elem_off<double>(16 * R + P::crow(q, r), 16 * C + lr));
     }
-    const __amdgpu_buffer_rsrc_t lres = gpcc_rsrc(Lt, GPCC_TILE_ELEMS * 8);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned smem_addr = gpcc_lds_addr(smem);
     const double *p0 = smem + lr * 16 + (((2 * q) ^ sw) * 2);
     const double *p1 = smem + lr * 16 + (((2 * q + 1) ^ sw) * 2);
     for (int ch = 0; ch < 8; ++ch) {
-        if (tid == 0) ctl[0] = gpcc_wait_ge(&colflag[ch], 4u, abortw, 0x100u + ch) ? 1 : 0;
-        __syncthreads();   // (also: every wave has finished the previous chunk's reads of the stage)
-        if (!ctl[0]) return false;
-        {
-            const d2 v0 = gpcc_ld16_sc1(lres, (unsigned)(ch * GPCC_CHUNK_BYTES + tid * 16));
-            const d2 v1 = gpcc_ld16_sc1(lres, (unsigned)(ch * GPCC_CHUNK_BYTES + (tid + 512) * 16));
-            *(d2 *)(smem + tid * 2) = v0;
-            *(d2 *)(smem + (tid + 512) * 2) = v1;
-        }
-        __syncthreads();
+        // every wave polls for itself (one lane) and copies ITS 2 KiB of the column block into stage ch & 1 by LDS-DMA the moment the
+        // fourth quarter has signalled it: one barrier per block (the stage written now was last read two blocks ago, and every wave
+        // has passed the barrier in between)
+        int okw = 1;
+        if (lane == 0) okw = gpcc_wait_ge(&colflag[ch], 4u, abortw, 0x100u + ch) ? 1 : 0;
+        okw = __builtin_amdgcn_readfirstlane(okw);
+        const int so = (ch & 1) * 2048;
+        if (okw) gpcc_dma_piece2_sc1(gpcc_uniform_ptr(Lt + ch * 2048 + wave * 256), (unsigned)lane * 16u, smem_addr + (unsigned)(so * 8 + wave * 2048));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!__syncthreads_and(okw)) return false;
         d2 aA[2], aB[2];
-        aA[0] = *(const d2 *)(p0 + RA * 16 * 16);
-        aA[1] = *(const d2 *)(p1 + RA * 16 * 16);
+        aA[0] = *(const d2 *)(p0 + so + RA * 16 * 16);
+        aA[1] = *(const d2 *)(p1 + so + RA * 16 * 16);
         if (NB > 0) {
-            aB[0] = *(const d2 *)(p0 + RB * 16 * 16);
-            aB[1] = *(const d2 *)(p1 + RB * 16 * 16);
+            aB[0] = *(const d2 *)(p0 + so + RB * 16 * 16);
+            aB[1] = *(const d2 *)(p1 + so + RB * 16 * 16);
         }
 #pragma unroll
         for (int i = 0; i < NA + NB; ++i) {
             const int C = (i < NA) ? CA + i : CB + (i - NA);
             d2 b[2];
-            b[0] = *(const d2 *)(p0 + C * 16 * 16);
-            b[1] = *(const d2 *)(p1 + C * 16 * 16);
+            b[0] = *(const d2 *)(p0 + so + C * 16 * 16);
+            b[1] = *(const d2 *)(p1 + so + C * 16 * 16);
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc[i] = P::mfma((i < NA) ? aA[s / 2][s % 2] : aB[s / 2][s % 2], b[s / 2][s % 2], acc[i]);
         }
@@ -524,7 +527,10 @@ GPCC_CHAIN_FN bool gpcc_chain_syrk_wave(const double *Tt, const double *Lt, cons
     for (int i = 0; i < NA + NB; ++i) {
         const int R = (i < NA) ? RA : RB, C = (i < NA) ? CA + i : CB + (i - NA);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) smem[gpcc_bi(R, C) + gpcc_be(P::crow(q, r), lr)] = -acc[i][r];
+        for (int r = 0; r < 4; ++r) {
+            smem[gpcc_bi(R, C) + gpcc_be(P::crow(q, r), lr)] = -acc[i][r];
+            if (R == 0 && C == 0) smem[GPCC_CHAIN_TMP_OFF + P::crow(q, r) * GPCC_CHAIN_TLD + lr] = -acc[i][r];   // the first block to be factored, row-major
+        }
     }
     return true;
 }
@@ -544,7 +550,7 @@ __device__ __forceinline__ void gpcc_chain_role(const GpccCtx &c, const GpccGrou
         int tid = tid0;
         asm volatile("" : "+v"(tid));   // per-step opaque copy: keeps the compiler from hoisting every lane-dependent address of a step out of this loop (spills)
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        unsigned long long *tr = a.trace ? a.trace + ((long)m * c.nt + k) * 4 : nullptr;
+        unsigned long long *tr = a.trace ? a.trace + ((long)m * c.nt + k) * GPCC_CHAIN_TRACE_WORDS : nullptr;
         if (tr && tid == 0) tr[0] = wall_clock64();
         const double *Tt = tiles + gpcc_tile_off(k, k);
         if (k == 0) {   // tile (0,0) as assembled (before the launch: plain loads): its lower 36 blocks -> image
@@ -556,6 +562,7 @@ __device__ __forceinline__ void gpcc_chain_role(const GpccCtx &c, const GpccGrou
                     const d2 v = *(const d2 *)(Tt + e);
                     smem[gpcc_bi(r >> 4, col0 >> 4) + gpcc_be(r & 15, col0 & 15)] = v[0];
                     smem[gpcc_bi(r >> 4, col0 >> 4) + gpcc_be(r & 15, (col0 & 15) + 1)] = v[1];
+                    if (r < 16 && col0 < 16) *(d2 *)(smem + GPCC_CHAIN_TMP_OFF + r * GPCC_CHAIN_TLD + col0) = v;
                 }
             }
         } else {
@@ -592,7 +599,7 @@ __device__ __forceinline__ void gpcc_chain_role(const GpccCtx &c, const GpccGrou
 // signalled separately (colflag[k][f]): the chain workgroup that builds tile (k+1,k+1) consumes them as they come.
 // ------------------------------------------------------------------------------------------
 GPCC_CHAIN_FN bool gpcc_chain_trsmq(const GpccCtx &c, const GpccChainArgs &a, const GpccChainFlags &fl, const int m, const int slot, const int k,
-                                    const int I, const int qr, double *smem, int *ctl, const int tid)
+                                    const int I, const int qr, double *smem, int *ctl, const int tid, unsigned long long *wt)
 {
     typedef GpccPrec<double> P;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -606,6 +613,7 @@ GPCC_CHAIN_FN bool gpcc_chain_trsmq(const GpccCtx &c, const GpccChainArgs &a, co
     if (tid == 0) ctl[0] = gpcc_wait_ge(&fl.ver[gpcc_tile_idx(I, k)], (unsigned)k, fl.abortw, 0x300u) ? 1 : 0;
     __syncthreads();
     if (!ctl[0]) return false;
+    if (wt && tid == 0) wt[2] = wall_clock64();
     // A operand: T(I,k)[32 qr + 16 rh + lr][16 ch + 4 q .. 4 q + 3] for this wave's chunks ch = kq, kq + 4
     d2 av[2][2];
     {
@@ -620,46 +628,84 @@ GPCC_CHAIN_FN bool gpcc_chain_trsmq(const GpccCtx &c, const GpccChainArgs &a, co
     // reducer threads (waves 0-3): (rh2, row, sp) = 16-byte slot sp (columns 2 sp, 2 sp + 1) of row 16 rh2 + row of the quarter
     const int rh2 = tid >> 7, rrow = (tid >> 3) & 15, sp = tid & 7;
     double lv[8][2];
-#pragma unroll
-    for (int f = 0; f < 8; ++f) {   // (unrolled: lv stays in registers)
-        if (tid == GPCC_CHAIN_THREADS - 64) ctl[0] = gpcc_wait_ge(&fl.xrow[k], (unsigned)(f + 1), fl.abortw, 0x310u + f) ? 1 : 0;   // (wave 7: not a reducer)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the reducers' stores of column block f - 1 have drained ...)
-        __syncthreads();
-        if (!ctl[0]) return false;
-        if (chain_tile && f > 0 && tid == 0) gpcc_flag_add(&fl.colflag[8 * k + f - 1], 1u);   // (... and ONE lane signals it)
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
+    int *cdone = ctl + 8;       // [8]: reducer waves that have drained their stores of column block f (LDS counters; the last one signals)
+    if (tid < 8) cdone[tid] = 0;
+    int seen = 0;               // rows of inv(L_kk) known to be published (uniform)
+    d2 bn[2][2];                // the next row block's operands, requested ahead when that row is known to be out already
+    bool have_next = false;
+    auto load_b = [&](int f, d2 (&b)[2][2]) {
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
             const int ch = kq + 4 * c2;
             if (ch <= f) {   // (wave-uniform)
                 const unsigned off = (unsigned)((gpcc_bi(f, ch) + lr * 16 + 4 * q) * 8);
-                const d2 b0 = gpcc_ld16_sc1(xres, off), b1 = gpcc_ld16_sc1(xres, off + 16u);
-                acc = P::mfma(av[c2][0][0], b0[0], acc);
-                acc = P::mfma(av[c2][0][1], b0[1], acc);
-                acc = P::mfma(av[c2][1][0], b1[0], acc);
-                acc = P::mfma(av[c2][1][1], b1[1], acc);
+                b[c2][0] = gpcc_ld16_sc1(xres, off);
+                b[c2][1] = gpcc_ld16_sc1(xres, off + 16u);
+            }
+        }
+    };
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {   // (unrolled: lv stays in registers)
+        const int need = (f < 7) ? f + 1 : 9;
+        if (seen < need) {          // caught up with the diagonal step: wait for its next row block (one lane polls; wave 7 is not a reducer)
+            if (tid == GPCC_CHAIN_THREADS - 64) {
+                ctl[0] = gpcc_wait_ge(&fl.xrow[k], (unsigned)need, fl.abortw, 0x310u + f) ? 1 : 0;
+                ctl[3] = (int)gpcc_flag_ld(&fl.xrow[k]);
+            }
+            __syncthreads();
+            if (!ctl[0]) return false;
+            seen = ctl[3];
+            __syncthreads();        // (ctl[3] is rewritten below)
+        }
+        d2 b[2][2];
+        if (have_next) {
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) { b[c2][0] = bn[c2][0]; b[c2][1] = bn[c2][1]; }
+        } else {
+            load_b(f, b);
+        }
+        have_next = (f < 7) && (seen >= ((f + 1 < 7) ? f + 2 : 9));
+        if (have_next) load_b(f + 1, bn);
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int ch = kq + 4 * c2;
+            if (ch <= f) {
+                acc = P::mfma(av[c2][0][0], b[c2][0][0], acc);
+                acc = P::mfma(av[c2][0][1], b[c2][0][1], acc);
+                acc = P::mfma(av[c2][1][0], b[c2][1][0], acc);
+                acc = P::mfma(av[c2][1][1], b[c2][1][1], acc);
             }
         }
         double *part = smem + (f & 1) * 2048 + wave * 256;   // [wave][row][col] of this column block's partials
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[P::crow(q, r) * 16 + lr] = acc[r];
+        if (tid == GPCC_CHAIN_THREADS - 64) ctl[3] = (int)gpcc_flag_ld(&fl.xrow[k]);   // (a look, not a wait: how far the diagonal step is by now)
         __syncthreads();
+        seen = ctl[3] > seen ? ctl[3] : seen;
         if (tid < 256) {
             const double *pp = smem + (f & 1) * 2048 + rh2 * 256 + rrow * 16 + 2 * sp;
-            d2 s = *(const d2 *)pp;                       // kq = 0
-            s += *(const d2 *)(pp + 2 * 256);            // kq = 1 (wave = 2 kq + rh)
-            s += *(const d2 *)(pp + 4 * 256);
-            s += *(const d2 *)(pp + 6 * 256);
-            lv[f][0] = s[0];
-            lv[f][1] = s[1];
+            d2 sm = *(const d2 *)pp;                      // kq = 0
+            sm += *(const d2 *)(pp + 2 * 256);            // kq = 1 (wave = 2 kq + rh)
+            sm += *(const d2 *)(pp + 4 * 256);
+            sm += *(const d2 *)(pp + 6 * 256);
+            lv[f][0] = sm[0];
+            lv[f][1] = sm[1];
             const int row = 32 * qr + 16 * rh2 + rrow;
-            gpcc_st16_sc1(tres, (unsigned)((f * 2048 + row * 16 + ((sp ^ gpcc_sw(row)) * 2)) * 8), s);
+            gpcc_st16_sc1(tres, (unsigned)((f * 2048 + row * 16 + ((sp ^ gpcc_sw(row)) * 2)) * 8), sm);
+            if (chain_tile) {
+                // column block f of L(k+1,k) is signalled the moment its four storing waves have drained: each adds to an LDS counter
+                // behind its own wait, the last one adds to the global counter the chain polls (no workgroup barrier in between)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                int last = 0;
+                if (lane == 0) last = (__hip_atomic_fetch_add(&cdone[f], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 3) ? 1 : 0;
+                if (last) gpcc_flag_add(&fl.colflag[8 * k + f], 1u);
+            }
         }
     }
-    // forward substitution of logpdf's whitening: z_I[row] -= sum_c L(I,k)[row][c] w_k[c]
-    if (tid == GPCC_CHAIN_THREADS - 64) ctl[0] = gpcc_wait_ge(&fl.xrow[k], 9u, fl.abortw, 0x320u) ? 1 : 0;
-    __syncthreads();
-    if (!ctl[0]) return false;
+    // forward substitution of logpdf's whitening: z_I[row] -= sum_c L(I,k)[row][c] w_k[c] -- AFTER the last column block is signalled
+    // (the chain folds it into tile (k+1,k+1) meanwhile; z_{k+1} is wanted a block step later: gpcc_chain_diag)
+    // (xrow = 9 was seen before column block 7: w_k is there)
     if (tid < 256) {
         const double *wp = c.w + (long)slot * c.nrhs * c.Np + k * GPCC_TILE;
         double pr = 0.0;
@@ -678,21 +724,18 @@ GPCC_CHAIN_FN bool gpcc_chain_trsmq(const GpccCtx &c, const GpccChainArgs &a, co
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
-        if (chain_tile) gpcc_flag_add(&fl.colflag[8 * k + 7], 1u);
-        gpcc_flag_add(&fl.lcnt[gpcc_tile_idx(I, k)], 1u);
-    }
+    if (tid == 0) gpcc_flag_add(&fl.lcnt[gpcc_tile_idx(I, k)], 1u);
     return true;
 }
 
 // ------------------------------------------------------------------------------------------
-// Worker job UPD(I, J, k): the right-looking trailing update T(I,J) -= L(I,k) L(J,k)^T of one tile (gpcc_small_step's tile job:
-// 8 waves x (32 x 64), operands by LDS-DMA into a 2-deep ring -- here with sc1 --, the result out through LDS in the tile's own
-// byte layout as 16-byte sc1 stores), once both column tiles are complete (lcnt = 4 quarters) and the tile has received column
-// k - 1 (ver = k).
+// Worker job UPD(I, J, k): the right-looking trailing update T(I,J) -= L(I,k) L(J,k)^T of one tile (8 waves x (32 x 64), operands by
+// LDS-DMA -- sc1 -- into a 3-deep ring, the result out through LDS in the tile's own byte layout as 16-byte sc1 stores), once both
+// column tiles are complete (lcnt = 4 quarters) and the tile has received
+// column k - 1 (ver = k).
 // ------------------------------------------------------------------------------------------
 GPCC_CHAIN_FN bool gpcc_chain_upd(const GpccCtx &c, const GpccChainFlags &fl, const int slot, const int k, const int I, const int J, double *smem,
-                                  int *ctl, const int tid)
+                                  int *ctl, const int tid, unsigned long long *wt)
 {
     typedef GpccPrec<double> P;
     constexpr int CH = 2048;
@@ -703,14 +746,22 @@ GPCC_CHAIN_FN bool gpcc_chain_upd(const GpccCtx &c, const GpccChainFlags &fl, co
         ok = ok && gpcc_wait_ge(&fl.lcnt[gpcc_tile_idx(J, k)], 4u, fl.abortw, 0x401u);
         ok = ok && gpcc_wait_ge(&fl.ver[gpcc_tile_idx(I, J)], (unsigned)k, fl.abortw, 0x402u);
         ctl[0] = ok ? 1 : 0;
+        if (wt) wt[2] = wall_clock64();
     }
     __syncthreads();
     if (!ctl[0]) return false;
     double *tiles = (double *)c.tiles + (long)slot * c.slot_stride;
     const double *gA = (const double *)gpcc_uniform_ptr(tiles + gpcc_tile_off(I, k)), *gB = (const double *)gpcc_uniform_ptr(tiles + gpcc_tile_off(J, k));
     double *Tt = tiles + gpcc_tile_off(I, J);
+    const __amdgpu_buffer_rsrc_t tres = gpcc_rsrc(Tt, GPCC_TILE_ELEMS * 8);
     const unsigned smem_addr = gpcc_lds_addr(smem);
+    // operands by LDS-DMA (sc1) into a ring of THREE 32 KiB stages, two chunks ahead (one workgroup per CU: nobody else hides the
+    // latency of a read that comes from another XCD's write-through).  The accumulators start at -T(I,J) like everywhere else in this
+    // library: forming the product from zero and subtracting it once at the end (the tile prefetched as linear pieces) was measured --
+    // no faster, and 20x less accurate on matrices with a large B term (1.3e-11 instead of 6e-13 at N = 4095): the running sum then
+    // never shrinks towards the Schur complement
     gpcc_dma_chunk_sc1(gA, gB, smem_addr, wave, lane);
+    gpcc_dma_chunk_sc1(gA + CH, gB + CH, smem_addr + 2 * GPCC_CHUNK_BYTES, wave, lane);
     d4 acc[2][4];
 #pragma unroll
     for (int fm = 0; fm < 2; ++fm)
@@ -722,13 +773,15 @@ GPCC_CHAIN_FN bool gpcc_chain_upd(const GpccCtx &c, const GpccChainFlags &fl, co
     const double *pa1 = smem + (wr * 32 + lr) * 16 + (((2 * q + 1) ^ sw) * 2);
     const double *pb0 = smem + CH + (wc * 64 + lr) * 16 + (((2 * q) ^ sw) * 2);
     const double *pb1 = smem + CH + (wc * 64 + lr) * 16 + (((2 * q + 1) ^ sw) * 2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll 2
+#pragma unroll
     for (int ch = 0; ch < 8; ++ch) {   // one tile of K: the chunks of L(I,k) and L(J,k)
-        const int st = ch & 1;
-        if (ch + 1 < 8) gpcc_dma_chunk_sc1(gA + (long)(ch + 1) * CH, gB + (long)(ch + 1) * CH, smem_addr + (st ^ 1) * 2 * GPCC_CHUNK_BYTES, wave, lane);
-        const int so = st * 2 * CH;
+        // chunk ch has landed (4 DMA instructions per wave and chunk; chunk ch + 1 may still fly); behind the barrier every wave has
+        // finished chunk ch - 1, whose stage takes chunk ch + 2
+        if (ch < 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ch + 2 < 8) gpcc_dma_chunk_sc1(gA + (long)(ch + 2) * CH, gB + (long)(ch + 2) * CH, smem_addr + ((ch + 2) % 3) * 2 * GPCC_CHUNK_BYTES, wave, lane);
+        const int so = (ch % 3) * 2 * CH;
         d2 a2[2][2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
@@ -744,19 +797,17 @@ GPCC_CHAIN_FN bool gpcc_chain_upd(const GpccCtx &c, const GpccChainFlags &fl, co
                 b[f][1] = *(const d2 *)(pb1 + so + (2 * h + f) * 16 * 16);
             }
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
                 for (int fm = 0; fm < 2; ++fm)
 #pragma unroll
-                    for (int f = 0; f < 2; ++f) acc[fm][2 * h + f] = P::mfma(a2[fm][s / 2][s % 2], b[f][s / 2][s % 2], acc[fm][2 * h + f]);
+                    for (int f = 0; f < 2; ++f) acc[fm][2 * h + f] = P::mfma(a2[fm][s2 / 2][s2 % 2], b[f][s2 / 2][s2 % 2], acc[fm][2 * h + f]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
     // out through LDS in the tile's own byte layout, rows 64 hv .. 64 hv + 63 at a time (64 KiB), then linear 16-byte sc1 stores
-    const __amdgpu_buffer_rsrc_t tres = gpcc_rsrc(Tt, GPCC_TILE_ELEMS * 8);
 #pragma unroll
     for (int hv = 0; hv < 2; ++hv) {
+        __syncthreads();   // (the stages -- resp. the previous half -- have been read)
         if ((wr >> 1) == hv) {
 #pragma unroll
             for (int fm = 0; fm < 2; ++fm)
@@ -772,7 +823,6 @@ GPCC_CHAIN_FN bool gpcc_chain_upd(const GpccCtx &c, const GpccChainFlags &fl, co
 #pragma unroll
         for (int ch = 0; ch < 8; ++ch)   // 512 sixteen-byte pieces per chunk and half: one per thread
             gpcc_st16_sc1(tres, (unsigned)((ch * CH + hv * 1024 + tid * 2) * 8), *(const d2 *)(smem + ch * 1024 + tid * 2));
-        if (hv == 0) __syncthreads();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -826,9 +876,19 @@ __global__ __launch_bounds__(GPCC_CHAIN_THREADS, 2) void gpcc_chain_kernel(GpccC
         if (j < 0) return;
         const int m = j % g.cnt, jj = j / g.cnt, k = ks, n = c.nt - k - 1, slot = g.slot0 + m;
         const GpccChainFlags fl = gpcc_chain_flags(a, c.nt, m);
+        unsigned long long *wt = nullptr;
+        if (a.wtrace) {
+            if (tid == 0) ctl[4] = (int)gpcc_flag_add(&a.words[1], 1u);
+            __syncthreads();
+            if (ctl[4] < a.wtrace_cap) wt = a.wtrace + 4L * ctl[4];
+            if (wt && tid == 0) {
+                wt[0] = ((unsigned long long)(jj < 4 * n ? 1 : 2) << 56) | ((unsigned long long)k << 32) | (unsigned)jj;
+                wt[1] = wall_clock64();
+            }
+        }
         bool ok;
         if (jj < 4 * n) {
-            ok = gpcc_chain_trsmq(c, a, fl, m, slot, k, k + 1 + jj / 4, jj % 4, smem, ctl, tid);
+            ok = gpcc_chain_trsmq(c, a, fl, m, slot, k, k + 1 + jj / 4, jj % 4, smem, ctl, tid, wt);
         } else {
             const int u = jj - 4 * n;
             int ra, rb;   // tile (k + 1 + ra, k + 1 + rb), rb <= ra, (0,0) excluded: column k + 1 first (the next step's solves wait for it)
@@ -843,9 +903,10 @@ __global__ __launch_bounds__(GPCC_CHAIN_THREADS, 2) void gpcc_chain_kernel(GpccC
                 ra = 1 + t;
                 rb = 1 + (v - t * (t + 1) / 2);
             }
-            ok = gpcc_chain_upd(c, fl, slot, k, k + 1 + ra, k + 1 + rb, smem, ctl, tid);
+            ok = gpcc_chain_upd(c, fl, slot, k, k + 1 + ra, k + 1 + rb, smem, ctl, tid, wt);
         }
         if (!ok) return;
+        if (wt && tid == 0) wt[3] = wall_clock64();
         __syncthreads();
     }
 }

@@ -666,8 +666,9 @@ static int ensure_chain(gpcc_handle_t h)
     HIPCHK(h, hipMalloc(&h->d_ximg, sizeof(double) * S * E * h->nt * GPCC_XIMG_ELEMS));
     HIPCHK(h, hipMalloc(&h->d_stepval, sizeof(double) * S * E * h->nt * GPCC_CHAIN_STEPVALS));
     if (h->chain_trace) {
-        HIPCHK(h, hipMalloc(&h->d_chain_trace, sizeof(unsigned long long) * S * E * h->nt * 4));
-        HIPCHK(h, hipMemset(h->d_chain_trace, 0, sizeof(unsigned long long) * S * E * h->nt * 4));
+        const size_t tw = (size_t)S * E * h->nt * GPCC_CHAIN_TRACE_WORDS + (size_t)S * 4 * GPCC_CHAIN_WTRACE_CAP;   // chain stamps, then the workers' jobs
+        HIPCHK(h, hipMalloc(&h->d_chain_trace, sizeof(unsigned long long) * tw));
+        HIPCHK(h, hipMemset(h->d_chain_trace, 0, sizeof(unsigned long long) * tw));
     }
     if (!h->n_cus) {
         int n = 0;
@@ -684,6 +685,22 @@ static bool takes_chain(gpcc_handle_t h, const GpccCtx &c, int cnt)
     return h->chain_max > 0 && cnt <= h->chain_max && cnt <= GPCC_CHAIN_MAX_EVALS && cnt <= h->right_looking_max && c.nt > 1 && c.nt_fact == c.nt &&
            !c.share_p && !c.store_l && c.nrhs == 1 && !c.woodbury && h->precision == GPCC_PRECISION_FP64 && c.tiles == (void *)h->d_tiles &&
            h->d_chain_words != nullptr && h->chain_streams == h->ws_streams;
+}
+
+// the buffers of the persistent launch for the group that starts at slot g.slot0 (one region per workspace stream)
+static GpccChainArgs chain_args(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g)
+{
+    const int si = g.slot0 / (h->ws_slots > 0 ? h->ws_slots : 1);
+    GpccChainArgs a;
+    a.words = h->d_chain_words + (long)si * h->chain_region_words;
+    a.ximg = h->d_ximg + (long)si * GPCC_CHAIN_MAX_EVALS * c.nt * GPCC_XIMG_ELEMS;
+    a.stepval = h->d_stepval + (long)si * GPCC_CHAIN_MAX_EVALS * c.nt * GPCC_CHAIN_STEPVALS;
+    a.trace = h->d_chain_trace ? h->d_chain_trace + (long)si * GPCC_CHAIN_MAX_EVALS * c.nt * GPCC_CHAIN_TRACE_WORDS : nullptr;
+    a.wtrace = h->d_chain_trace ? h->d_chain_trace + (size_t)h->ws_streams * GPCC_CHAIN_MAX_EVALS * c.nt * GPCC_CHAIN_TRACE_WORDS + (size_t)si * 4 * GPCC_CHAIN_WTRACE_CAP : nullptr;
+    a.wtrace_cap = GPCC_CHAIN_WTRACE_CAP;
+    a.ev_words = h->chain_ev_words;
+    a.qbase = h->chain_qbase;
+    return a;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -760,6 +777,7 @@ static GpccCtx make_ctx(gpcc_handle_t h)
     c.L = h->L; c.N = h->N; c.Np = h->Np; c.nt = h->nt; c.kernel_id = h->kernel_id; c.marginalise_b = h->mb;
     c.nt_fact = h->nt;
     c.nrhs = h->nrhs; c.woodbury = h->woodbury; c.share_p = 0; c.store_l = 0;
+    c.chain_words = nullptr; c.chain_qbase = 0; c.chain_ev_words = 0;
     c.asm32 = (h->precision == GPCC_PRECISION_FP32 && h->fp32_assemble && h->fp32_refine) ? 1 : 0;
     return c;
 }
@@ -832,6 +850,10 @@ static int enqueue_group(gpcc_handle_t h, const GpccCtx &c_in, const GpccGroup &
         default: gpcc_sep_points<3><<<grid, GPCC_TILE, 0, s>>>(c, g); break;
         }
     }
+    if (factor && !ext && !single && takes_chain(h, c, g.cnt)) {   // the assembly zeroes the flag words of the persistent launch that follows
+        const GpccChainArgs ca = chain_args(h, c, g);
+        c.chain_words = ca.words; c.chain_qbase = ca.qbase; c.chain_ev_words = ca.ev_words;
+    }
     launch_assemble(h, c, g, s, ext, single);
     if (!factor) return 0;
     int rc = enqueue_factor(h, c, g, s, single, concurrent);
@@ -874,18 +896,9 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
     const int p = c.share_p;   // shared prefix: steps k < p only involve the leader's rows < p and everyone's rows >= p
     if (sizeof(T) == 8 && right && takes_chain(h, c, g.cnt)) {
         // a few evaluations on an fp64 handle: ONE persistent launch -- two chain workgroups per evaluation, everybody else pulls jobs
-        // (gpcc_chain.hip.h); its flag words are zeroed on the stream first
+        // (gpcc_chain.hip.h)
         ProfScope pr(h, GPCC_PROF_SMALL_STEP, s);
-        const int si = g.slot0 / (h->ws_slots > 0 ? h->ws_slots : 1);
-        GpccChainArgs a;
-        a.words = h->d_chain_words + (long)si * h->chain_region_words;
-        a.ximg = h->d_ximg + (long)si * GPCC_CHAIN_MAX_EVALS * c.nt * GPCC_XIMG_ELEMS;
-        a.stepval = h->d_stepval + (long)si * GPCC_CHAIN_MAX_EVALS * c.nt * GPCC_CHAIN_STEPVALS;
-        a.trace = h->d_chain_trace ? h->d_chain_trace + (long)si * GPCC_CHAIN_MAX_EVALS * c.nt * 4 : nullptr;
-        a.ev_words = h->chain_ev_words;
-        a.qbase = h->chain_qbase;
-        const long used = ((long)a.qbase + (long)g.cnt * a.ev_words + 3) / 4 * 4;
-        (void)hipMemsetAsync(a.words, 0, sizeof(unsigned) * used, s);
+        const GpccChainArgs a = chain_args(h, c, g);   // (its flag words were zeroed by the assembly launch in front: GpccCtx::chain_words)
         const int ncb = 16 * ((g.cnt + 7) / 8);
         long workers = (long)g.cnt * gpcc_chain_jobs(c.nt - 1);   // the widest step; more workgroups than that would only spin
         const long room = (long)h->n_cus - 2 * g.cnt;
@@ -1352,6 +1365,39 @@ extern "C" int gpcc_loglik_batch(gpcc_handle_t h, int M, const double *delays, c
         memcpy(loglik, ln.ll, sizeof(double) * M);
         memcpy(info, ln.info, sizeof(int) * M);
         return 0;
+    }
+    if (h->precision == GPCC_PRECISION_FP64 && h->chain_max > 0 && M <= h->chain_max && M <= h->right_looking_max && M <= GPCC_CHAIN_MAX_EVALS &&
+        h->nt > 1 && !h->prof) {
+        // One objective(alpha, rho) (marginaliseb.jl:133-141 as Optim calls it, :145-153): the whole call is pack -> two launches (assembly,
+        // persistent factorisation) on workspace stream 0 -> one stream synchronisation.  Parameters are read from, results written to
+        // pinned, device-mapped host memory by the kernels themselves: no copy calls, no events (the general path below costs ~50 us
+        // more per call in runtime calls alone -- a quarter of an evaluation at N = 512)
+        int rc = ensure_workspace(h);
+        if (!rc) rc = ensure_chain(h);
+        if (!rc) rc = ensure_lane(h, 0, M);
+        if (rc) return rc;
+        SmallLane &ln = h->lanes[0];
+        const long ML = (long)M * h->L;
+        memcpy(ln.par, delays, sizeof(double) * ML);
+        memcpy(ln.par + ML, alpha, sizeof(double) * ML);
+        memcpy(ln.par + 2 * ML, rho, sizeof(double) * M);
+        const GpccCtx c = make_ctx(h);
+        GpccGroup g;
+        g.delays = ln.par; g.alpha = ln.par + ML; g.rho = ln.par + 2 * ML;
+        g.out_loglik = ln.ll; g.out_info = ln.info; g.out_cond = nullptr;
+        g.first = 0; g.slot0 = 0; g.cnt = M; g.spread = 0;
+        if (takes_chain(h, c, M)) {
+            rc = enqueue_group(h, c, g, h->str[0]);
+            if (rc) { (void)hipStreamSynchronize(h->str[0]); return rc; }
+            HIPCHK(h, hipStreamSynchronize(h->str[0]));
+            memcpy(loglik, ln.ll, sizeof(double) * M);
+            memcpy(info, ln.info, sizeof(int) * M);
+            for (int i = 0; i < M; ++i)
+                if (info[i] == GPCC_INFO_TIMEOUT)
+                    return fail(h, GPCC_ERR_STATE, "the persistent few-evaluation launch was abandoned (a bounded wait expired: evaluation %d); "
+                                                   "gpcc_set_option(handle, \"chain_max\", 0) selects the launch-per-step path", i);
+            return 0;
+        }
     }
     int rc = enqueue_host_batch(h, M, delays, alpha, rho, nullptr, nullptr);
     if (rc) return rc;
@@ -2377,16 +2423,46 @@ extern "C" int gpcc_chain_trace(gpcc_handle_t h, int evaluation, double *out_us,
     if (!h || !out_us) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
     h = primary(h);
     if (!h->d_chain_trace) return fail(h, GPCC_ERR_STATE, "no trace: set option \"chain_trace\" to 1 before the evaluation");
-    if (evaluation < 0 || evaluation >= GPCC_CHAIN_MAX_EVALS || capacity < 4 * h->nt) return fail(h, GPCC_ERR_ARGUMENT, "evaluation %d / capacity %d (need 4 nt = %d)", evaluation, capacity, 4 * h->nt);
+    const int W = GPCC_CHAIN_TRACE_WORDS;
+    if (evaluation < 0 || evaluation >= GPCC_CHAIN_MAX_EVALS || capacity < W * h->nt) return fail(h, GPCC_ERR_ARGUMENT, "evaluation %d / capacity %d (need %d nt = %d)", evaluation, capacity, W, W * h->nt);
     GPCC_ON_DEVICE(h, h->device);
     HIPCHK(h, hipDeviceSynchronize());
-    std::vector<unsigned long long> st(4 * (size_t)h->nt);
-    HIPCHK(h, hipMemcpy(st.data(), h->d_chain_trace + (long)evaluation * h->nt * 4, sizeof(unsigned long long) * st.size(), hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> st((size_t)W * h->nt);
+    HIPCHK(h, hipMemcpy(st.data(), h->d_chain_trace + (long)evaluation * h->nt * W, sizeof(unsigned long long) * st.size(), hipMemcpyDeviceToHost));
     int khz = 100000;
     (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device);
     unsigned long long t0 = ~0ull;
     for (unsigned long long v : st) if (v && v < t0) t0 = v;
     for (size_t i = 0; i < st.size(); ++i) out_us[i] = st[i] ? (double)(st[i] - t0) * 1e3 / khz : -1.0;
+    return 0;
+}
+
+// the job stamps of the last persistent launch on workspace stream 0: rows [kind (1 solve, 2 update), step, index in the step, fetched, ready, done] (us)
+extern "C" int gpcc_chain_jobs_trace(gpcc_handle_t h, double *out, long capacity_rows, long *rows_out)
+{
+    if (!h || !out || !rows_out) return fail(h, GPCC_ERR_ARGUMENT, "NULL pointer");
+    h = primary(h);
+    if (!h->d_chain_trace) return fail(h, GPCC_ERR_STATE, "no trace: set option \"chain_trace\" to 1 before the evaluation");
+    GPCC_ON_DEVICE(h, h->device);
+    HIPCHK(h, hipDeviceSynchronize());
+    unsigned cnt = 0;
+    HIPCHK(h, hipMemcpy(&cnt, h->d_chain_words + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
+    long n = cnt < GPCC_CHAIN_WTRACE_CAP ? cnt : GPCC_CHAIN_WTRACE_CAP;
+    if (n > capacity_rows) n = capacity_rows;
+    std::vector<unsigned long long> st(4 * (size_t)(n > 0 ? n : 1));
+    const unsigned long long *src = h->d_chain_trace + (size_t)h->ws_streams * GPCC_CHAIN_MAX_EVALS * h->nt * GPCC_CHAIN_TRACE_WORDS;
+    if (n > 0) HIPCHK(h, hipMemcpy(st.data(), src, sizeof(unsigned long long) * 4 * n, hipMemcpyDeviceToHost));
+    int khz = 100000;
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device);
+    unsigned long long t0 = ~0ull;
+    for (long i = 0; i < n; ++i) if (st[4 * i + 1] && st[4 * i + 1] < t0) t0 = st[4 * i + 1];
+    for (long i = 0; i < n; ++i) {
+        out[6 * i] = (double)(st[4 * i] >> 56);
+        out[6 * i + 1] = (double)((st[4 * i] >> 32) & 0xffffff);
+        out[6 * i + 2] = (double)(st[4 * i] & 0xffffffffu);
+        for (int e = 1; e < 4; ++e) out[6 * i + 2 + e] = st[4 * i + e] ? (double)(st[4 * i + e] - t0) * 1e3 / khz : -1.0;
+    }
+    *rows_out = n;
     return 0;
 }
 

@@ -102,6 +102,8 @@ struct GpccCtx {
     int store_l;   // gpcc_diag_factor also writes L_kk back (dense factor export); 0 on the log-likelihood path
     int woodbury;  // 1: the matrix is K0 = delayedCovariance + Sobs only; B = Q Sigma_b Q' enters through the
                    //    L x L capacitance matrix in fp64 (determinant lemma + Woodbury) -- the fp32 path
+    unsigned *chain_words;          // != NULL: the group goes on into the persistent few-evaluation launch (gpcc_chain.hip.h), whose flag
+    int chain_qbase, chain_ev_words;   // words gpcc_assemble_tiles zeroes on the way (header [0, qbase), then ev_words per evaluation)
 };
 
 struct GpccGroup {
@@ -638,6 +640,12 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 4) void gpcc_assemble_til
         c.logdet[slot] = 0.0;
         for (int i = 0; i < c.nrhs * c.nrhs; ++i) c.gram[(long)slot * GPCC_MAXRHS * GPCC_MAXRHS + i] = 0.0;
         if (sizeof(T) == 4 && c.cond) c.cond[2 * (long)slot] = c.cond[2 * (long)slot + 1] = 0.0;
+    }
+    if (c.chain_words && I == first_row && J == 0) {   // the flag words of the launch that follows (a kernel boundary away): all zero
+        unsigned *wz = c.chain_words + c.chain_qbase + (long)m * c.chain_ev_words;
+        for (int i = tid; i < c.chain_ev_words; i += 256) wz[i] = 0u;
+        if (m == 0)
+            for (int i = tid; i < c.chain_qbase; i += 256) c.chain_words[i] = 0u;
     }
     {
         const int side = tid >> 7, r = tid & 127;
@@ -1576,6 +1584,121 @@ __device__ __forceinline__ double gpcc_rsqrt(double d)
     return __builtin_fma(y, r, y);
 }
 
+// ------------------------------------------------------------------------------------------
+// gpcc_potf2_core: the 16 x 16 Cholesky + inverse in the registers of ONE wave -- the serial heart of every diagonal step (tile
+// kernels: gpcc_diag_body; the persistent few-evaluation launch: gpcc_chain_diag; the small-N family: gpcc_small_potf2).
+// Lanes 0-15 own the rows of D (v[cc] = D[l][cc]), lanes 16-31 the columns of X = inv(L_D) (v[cc] = delta(cc, l) on entry), ONE
+// right-looking instruction stream for both: once column j of L is final, v[j] <- v[j] / sqrt(d_j) is L[l][j] on an L lane and
+// X[j][l] on an X lane, and the same v[cc] -= v[j] L[cc][j] updates the trailing row and the running sums of the inverse.
+// Round 5: the pivot-to-pivot chain no longer goes through a lane broadcast.  The next pivot
+//     d_{j+1} = A_j[j+1][j+1] - (A_j[j+1][j] / sqrt(d_j))^2
+// needs two entries of row j + 1 in their state BEFORE pivot j -- both known while 1/sqrt(d_j) is still being computed -- so they are
+// broadcast (v_readlane) early, off the chain, and d_{j+1} = fma(-lnx, lnx, e) with lnx = c y follows y in two operations on values
+// every lane holds.  Likewise the entry of row j + 2 that column j + 2's update needs (g): columns j + 1 and j + 2 receive pivot j's
+// update at once from uniform multipliers, the other columns one pivot later from the column broadcast through LDS (one store,
+// uniform-address loads), whose round trip is then two pivots off the chain.  Chain per pivot: mul -> fma -> v_rsq_f64 -> two Newton
+// steps = 9 dependent operations (it was those + 2 broadcasts + their hazard waits); the independent rank-1 updates are written
+// BETWEEN the dependent operations and pinned there (sched_barrier): the compiler's own schedule put them behind the chain, so that
+// wave 0 -- one in-order instruction stream -- paid chain latency PLUS their issue time, ~330 cycles per pivot.
+// Every value is formed by the same operations on the same operands as before: the same bits (1/sqrt(d): v_rsq_f64 + two Newton
+// steps, ~1 ulp; L_jj = d / sqrt(d)).  sum log L_jj of the block = -log prod 1/sqrt(d_j): the running product py (renormalised every
+// four pivots: mantissa py, exponent sum pe -- no overflow whatever the scale of K).
+// RHS (small-N family): with `last`, pivot 15 is the right-hand-side row -- its Schur complement is -w'w (quad), not a pivot.
+// TRACK (fp32 tile path): sum and maximum of K_ii / d_i over the pivots (skd = diag(K) of these 16 rows).
+// Returns j + 1 for the first non-positive (or NaN) pivot j, 0 if none.  sr: 80 doubles of LDS scratch.
+// ------------------------------------------------------------------------------------------
+template <bool RHS, bool TRACK>
+__device__ __forceinline__ int gpcc_potf2_core(double (&v)[16], double *sr, const int lrv, const int qv, const int lane, const bool last, double &py, int &pe,
+                                               double &quad, const double *skd, double &rs, double &rm)
+{
+    double cn[2][16];   // column j of D BEFORE its scaling, broadcast through LDS: set j & 1 (loaded during pivot j, consumed during pivot j + 1)
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) cn[0][cc] = cn[1][cc] = 0.0;
+    double d = gpcc_bcast(v[0], 0), wp = 0.0;
+    int bad = 0;
+    __builtin_amdgcn_sched_barrier(0);
+    // pivot j - 1's update of column cc >= j + 2, one pivot late: v[cc] -= L[l][j-1] L[cc][j-1] = (v[j-1] y y) * (column entry before scaling)
+#define GPCC_POTF2_FILL(k)                                                                                        \
+    do {                                                                                                          \
+        if (j >= 1 && j + 2 + (k) <= 15) v[j + 2 + (k)] = __builtin_fma(-wp, cn[(j - 1) & 1][j + 2 + (k)], v[j + 2 + (k)]); \
+    } while (0)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (RHS && j == 15 && last) {   // the right-hand-side row: its Schur complement is -w'w; not a pivot
+            quad = -d;
+            d = 1.0;
+        }
+        if (__builtin_amdgcn_fcmp(d, 0.0, 2 /* ordered > */) == 0ull && bad == 0) bad = j + 1;   // (d is the same in every lane: scalar; also catches NaN)
+        const double hd = -0.5 * d;
+        double y = __builtin_amdgcn_rsq(d);
+        // off the chain, while 1/sqrt(d) is on its way: the entries of rows j + 1, j + 2 the NEXT pivot needs (columns j and j + 1 are
+        // in their final pre-pivot state), and column j itself -- unscaled -- through LDS for the updates of the columns beyond j + 2
+        double cj = 0.0, ej = 0.0, gj = 0.0;
+        if (j < 15) {
+            cj = gpcc_bcast(v[j], j + 1);
+            ej = gpcc_bcast(v[j + 1], j + 1);
+        }
+        if (j < 14) gj = gpcc_bcast(v[j], j + 2);
+        if (j < 13) {
+            sr[qv == 0 ? lrv : 16 + lane] = v[j];   // (the other lanes store to a dead area: no branch)
+#pragma unroll
+            for (int cc = j + 3; cc < 16; ++cc) cn[j & 1][cc] = sr[cc];
+        }
+        GPCC_POTF2_FILL(0);
+        __builtin_amdgcn_sched_barrier(0);
+        double t = y * y;                       // Newton: y <- y + y (1/2 - (d/2) y^2), twice
+        GPCC_POTF2_FILL(1);
+        __builtin_amdgcn_sched_barrier(0);
+        double r = __builtin_fma(hd, t, 0.5);
+        GPCC_POTF2_FILL(2);
+        __builtin_amdgcn_sched_barrier(0);
+        y = __builtin_fma(y, r, y);
+        GPCC_POTF2_FILL(3);
+        __builtin_amdgcn_sched_barrier(0);
+        t = y * y;
+        GPCC_POTF2_FILL(4);
+        __builtin_amdgcn_sched_barrier(0);
+        r = __builtin_fma(hd, t, 0.5);
+        GPCC_POTF2_FILL(5);
+        __builtin_amdgcn_sched_barrier(0);
+        y = __builtin_fma(y, r, y);
+        GPCC_POTF2_FILL(6);
+        __builtin_amdgcn_sched_barrier(0);
+        double lnx = 0.0;
+        if (j < 15) lnx = cj * y;               // L[j+1][j]
+        GPCC_POTF2_FILL(7);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j < 15) d = __builtin_fma(-lnx, lnx, ej);   // the next pivot: its v_rsq_f64 is the next instruction of the chain
+        __builtin_amdgcn_sched_barrier(0);
+        GPCC_POTF2_FILL(8);
+        GPCC_POTF2_FILL(9);
+        GPCC_POTF2_FILL(10);
+        GPCC_POTF2_FILL(11);
+        GPCC_POTF2_FILL(12);
+        GPCC_POTF2_FILL(13);
+        py *= y;
+        if ((j & 3) == 3) {
+            pe += __builtin_amdgcn_frexp_exp(py);
+            py = __builtin_amdgcn_frexp_mant(py);
+        }
+        if (TRACK) {
+            const double ratio = skd[j] * (y * y);
+            rs += ratio;
+            rm = fmax(rm, ratio);
+        }
+        v[j] *= y;                              // L[l][j]; lane j: L[j][j] = d / sqrt(d)
+        if (j < 15) v[j + 1] = __builtin_fma(-v[j], lnx, v[j + 1]);
+        if (j < 14) {
+            const double lg = gj * y;           // L[j+2][j]
+            v[j + 2] = __builtin_fma(-v[j], lg, v[j + 2]);
+        }
+        if (j < 13) wp = v[j] * y;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef GPCC_POTF2_FILL
+    return bad;
+}
+
 // loglik = -(N log 2pi + logdet K)/2 - (Y-bbar)' K^-1 (Y-bbar)/2  (Distributions.logpdf, marginaliseb.jl:139) from
 // ld = sum_i log L_ii and the Gram matrix G = W'W of the whitened right-hand sides (nrhs x nrhs, modified in place).
 // woodbury: the matrix that was factorised is K0 and R = [Q | r]:
@@ -1721,34 +1844,11 @@ __device__ __forceinline__ void gpcc_diag_body(const GpccCtx &c, const GpccGroup
                 const double *row = sT + (r0 + lr) * LD + r0;   // 16 contiguous doubles, 16-byte aligned
 #pragma unroll
                 for (int cc = 0; cc < 16; ++cc) v[cc] = xl ? ((cc == lr) ? 1.0 : 0.0) : row[cc];
-                int bad = 0;
-                double py = 1.0;   // prod of the mantissas of 1/sqrt(d_j) (>= 2^-16) ...
-                int pe = 0;        // ... and the sum of their exponents: no overflow whatever the scale of K
-                double rs = 0.0, rm = 0.0;   // sum and max of K_ii / d_i over this block's pivots (fp32 mode only)
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const double d = gpcc_bcast(v[j], j);
-                    if (!(d > 0.0) && bad == 0) bad = j + 1;  // also catches NaN
-                    const double y = gpcc_rsqrt(d);
-                    py *= __builtin_amdgcn_frexp_mant(y);   // off the chain: sum log L_jj of the block = -log prod 1/sqrt(d_j)
-                    pe += __builtin_amdgcn_frexp_exp(y);
-                    if (sizeof(T) == 4 && track) {   // off the chain too
-                        const double ratio = skd[r0 + j] * (y * y);
-                        rs += ratio;
-                        rm = fmax(rm, ratio);
-                    }
-                    v[j] *= y;               // lane j: L[j][j] = d / sqrt(d)
-                    if (j < 15) {
-                        // L[j+1][j] feeds the next pivot: v_readlane (short latency).  The other entries of the column go
-                        // through LDS (one masked store, uniform-address loads): a third of the instructions of 2
-                        // readlanes per value, and their round trip is off the pivot-to-pivot chain.
-                        sr[q == 0 ? lr : 16 + lane] = v[j];   // (the other lanes store to a dead area: no branch)
-                        const double lnx = gpcc_bcast(v[j], j + 1);
-                        v[j + 1] = __builtin_fma(-v[j], lnx, v[j + 1]);
-#pragma unroll
-                        for (int cc = j + 2; cc < 16; ++cc) v[cc] = __builtin_fma(-v[j], sr[cc], v[cc]);
-                    }
-                }
+                double py = 1.0;   // prod of 1/sqrt(d_j) as mantissa ...
+                int pe = 0;        // ... and exponent: no overflow whatever the scale of K
+                double rs = 0.0, rm = 0.0, quad_ = 0.0;   // sum and max of K_ii / d_i over this block's pivots (fp32 mode only)
+                const int bad = (sizeof(T) == 4 && track) ? gpcc_potf2_core<false, true>(v, sr, lr, q, lane, false, py, pe, quad_, skd + r0, rs, rm)
+                                                          : gpcc_potf2_core<false, false>(v, sr, lr, q, lane, false, py, pe, quad_, skd + r0, rs, rm);
                 if (lane < 32) {
                     // row l of L_D (its entries right of the diagonal are dead values in a dead area) resp. column l of
                     // X (exact zeros above the diagonal): 16 contiguous stores from every lane, no masks

@@ -274,11 +274,15 @@ int gpcc_profile_get(gpcc_handle_t handle, int which, long *launches, double *to
 /* On-device self-test of the f64 MFMA fragment maps and a timing probe of the fp64 MFMA rate:
  * returns 0 when the maps are as the kernels assume; *tflops (may be NULL) = measured rate. */
 /* Measurement plumbing of the persistent few-evaluation launch (option "chain_max"): with option "chain_trace" = 1 its chain
- * workgroups stamp the device's wall clock per diagonal step k; out_us[4 k + 0 / 1 / 2] = microseconds (from the first stamp of the
- * evaluation) at which the workgroup of step k began to build tile (k,k), had it complete (first pivot next), had published the whole
- * step; -1 where nothing was stamped.  `evaluation` = index in the last group of at most chain_max evaluations; capacity >= 4 nt
- * doubles (nt = Np / 128).  tools/chain_trace.py prints the critical chain from it. */
+ * workgroups stamp the device's wall clock per diagonal step k, 80 stamps each; out_us[80 k + 0 / 1 / 2] = microseconds (from the
+ * first stamp of the evaluation) at which the workgroup of step k began to build tile (k,k), had it complete (first pivot next), had
+ * published the whole step; [80 k + 8 + 8 jb + 0 .. 7] = block step jb of the diagonal step: begins, wave 0 done, behind its first
+ * barrier, behind its second; wave 0: fold done, block loaded, factored, stored; -1 where nothing was stamped.  `evaluation` = index in the last group of at most
+ * chain_max evaluations; capacity >= 80 nt doubles (nt = Np / 128).  tools/chain_trace.py prints the critical chain from it. */
 int gpcc_chain_trace(gpcc_handle_t handle, int evaluation, double *out_us, int capacity);
+/* ... and the workers' jobs of the same launch: rows of 6 doubles [kind (1 quarter-tile solve, 2 tile update), step k, index in the step,
+ * fetched, dependencies met, done] (microseconds from the first fetch), at most capacity_rows (32768 are kept per launch). */
+int gpcc_chain_jobs_trace(gpcc_handle_t handle, double *out, long capacity_rows, long *rows_out);
 
 int gpcc_selftest(int device_id, double *mfma_f64_tflops);
 

@@ -43,5 +43,24 @@ with gpcc_amd.Objective(t, y, s, "matern32", slots_per_stream=16) as obj:
             diag.append(dg)
             if k % args.every == 0 or k == nt - 1:
                 print("%4d %12.2f %12.2f %12.2f | %10.2f %10.2f %10.2f" % (k, tr[k, 0], tr[k, 1], tr[k, 2], h, dg, tr[k, 1] - tr[k, 0]))
+        ks = nt // 2
+        b = tr[ks, 8:80].reshape(9, 8)
+        print("block steps of diagonal step %d (us): wave 0 [fold | load block | 16 pivots | store] | wait at barrier 1 | inverse row + panel | total" % ks)
+        for jb in range(9):
+            nxt = b[jb + 1, 0] if jb < 8 else tr[ks, 2]
+            w0 = "%5.2f | %5.2f | %5.2f | %5.2f" % (b[jb, 4] - b[jb, 0], b[jb, 5] - b[jb, 4], b[jb, 6] - b[jb, 5], b[jb, 7] - b[jb, 6]) if jb < 8 else "%5.2f (last row of the inverse, W)     " % (b[jb, 1] - b[jb, 0])
+            print("   jb %d: %s | %5.2f | %5.2f | %5.2f" % (jb, w0, b[jb, 2] - b[jb, 1], (b[jb, 3] if jb < 8 else nxt) - b[jb, 2], nxt - b[jb, 0]))
         print("sum of hand-offs %.1f us (mean %.2f), sum of diagonal steps %.1f us (mean %.2f)" % (
             sum(hand[1:]), np.mean(hand[1:]) if nt > 1 else 0.0, sum(diag), np.mean(diag)))
+    jt = obj.chain_jobs_trace()
+    if len(jt):
+        print("== workers: %d jobs stamped (whole group)" % len(jt))
+        for kind, name in ((1, "quarter-tile solve"), (2, "tile update")):
+            r = jt[jt[:, 0] == kind]
+            if len(r):
+                wait, run = r[:, 4] - r[:, 3], r[:, 5] - r[:, 4]
+                print("   %-18s: %6d jobs, waiting for dependencies mean %6.2f us (median %6.2f, max %7.2f), running mean %6.2f us (median %6.2f, max %6.2f)" % (
+                    name, len(r), wait.mean(), np.median(wait), wait.max(), run.mean(), np.median(run), run.max()))
+        span = jt[:, 5].max() - jt[:, 3].min()
+        busy = (jt[:, 5] - jt[:, 4]).sum()
+        print("   span %.1f us; sum of running time %.1f us = %.1f workgroups busy on average" % (span, busy, busy / span))
