@@ -514,7 +514,7 @@ __device__ __forceinline__ void gpcc_fold_init_mixed(ACC (&acc)[8], double ui, d
         }
 }
 template <int KID, typename T, typename ACC>
-__device__ __forceinline__ void gpcc_fold_init_pu_mixed(ACC (&acc)[2][4], const double *rp, const double *cp, long Np, double s, const GpccCtx &c,
+__device__ __forceinline__ void gpcc_fold_init_pu_mixed(ACC (&acc)[2][4], const double *rp, const double *cp, long Np, double s, const double *ssb /* LDS: Sigma_b per band, 0 where B is not added */,
                                                         const int *rb, const int *cb, int q)
 {
     typedef GpccPrec<T> P;
@@ -534,7 +534,7 @@ __device__ __forceinline__ void gpcc_fold_init_pu_mixed(ACC (&acc)[2][4], const 
             const int i = fm * 16 + P::crow(q, r);
             const double ui = rp[i], Ai = rp[Np + i], Bi = rp[2 * Np + i];
             const int br = rb[i];
-            const double bterm = gpcc_fold_bterm(c, br);
+            const double bterm = (br >= 0) ? ssb[br] : 0.0;   // (LDS: the selects over the kernel argument cost 16 SGPRs, and those spilled into VGPRs)
 #pragma unroll
             for (int fn = 0; fn < 4; ++fn) acc[fm][fn][r] = -(T)gpcc_fold_mixed<KID>(ui, uj[fn], Ai, Bi, Aj[fn], Bj[fn], s, br, bj[fn], bterm);
         }
@@ -973,6 +973,11 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
 
     const unsigned smem_addr = gpcc_lds_addr(smem);
     gpcc_dma_chunk_at<T>(gA, gB, smem_addr, wave, lane);
+    __shared__ double s_sb[MIXED ? GPCC_MAXL : 1];   // Sigma_b of the bands (what gpcc_fold_bterm selects from the kernel argument), for the mixed fold
+    if (MIXED) {
+        if (tid < GPCC_MAXL) s_sb[tid] = (c.marginalise_b != 0 && !c.woodbury) ? c.sigma_b[tid] : 0.0;
+        __syncthreads();
+    }
 
     typename P::acc_t acc[2][4];
     // fold = 2 (round 4): the FIRST job that touches an off-diagonal tile (I,J), J >= 1 -- the left-looking update of column J, or the
@@ -1000,9 +1005,9 @@ __global__ __launch_bounds__(512, 4) void gpcc_panel_update(GpccCtx c, GpccGroup
             else gpcc_fold_init_pu_direct<3, T>(acc, rp, cp, Np, s, bt, q);
         } else if (MIXED && fmode == 3) {
             const int *rb = c.band + I * GPCC_TILE + wr * 32, *cb = c.band + J * GPCC_TILE + wc * 64 + lr;
-            if (c.kernel_id == 0) gpcc_fold_init_pu_mixed<0, T>(acc, rp, cp, Np, s, c, rb, cb, q);
-            else if (c.kernel_id == 2) gpcc_fold_init_pu_mixed<2, T>(acc, rp, cp, Np, s, c, rb, cb, q);
-            else gpcc_fold_init_pu_mixed<3, T>(acc, rp, cp, Np, s, c, rb, cb, q);
+            if (c.kernel_id == 0) gpcc_fold_init_pu_mixed<0, T>(acc, rp, cp, Np, s, s_sb, rb, cb, q);
+            else if (c.kernel_id == 2) gpcc_fold_init_pu_mixed<2, T>(acc, rp, cp, Np, s, s_sb, rb, cb, q);
+            else gpcc_fold_init_pu_mixed<3, T>(acc, rp, cp, Np, s, s_sb, rb, cb, q);
         } else {
             if (c.kernel_id == 0) gpcc_fold_init_pu<0, 1, T>(acc, rp, cp, Np, s, bt, c1, c2, q);
             else if (c.kernel_id == 2) gpcc_fold_init_pu<2, 1, T>(acc, rp, cp, Np, s, bt, c1, c2, q);
@@ -2655,7 +2660,7 @@ static __global__ __launch_bounds__(256) void gpcc_refine_finish(GpccCtx c, Gpcc
         __syncthreads();
     }
     if (tid == 0) {
-        double G[GPCC_MAXRHS * GPCC_MAXRHS];
+        double *G = sacc;   // (the reduction buffer is free by now; a local array indexed at run time lived in 656 B of private memory)
         for (int a = 0; a < nrhs; ++a)
             for (int b = 0; b < nrhs; ++b) G[a * nrhs + b] = (sXR[a * nrhs + b] + sXR[b * nrhs + a]) - 0.5 * (sG[a * nrhs + b] + sG[b * nrhs + a]);
         int bad = 0;

@@ -56,18 +56,50 @@
 #define GPCC_SMALL_LEAN(NB) ((NB) == 9 || (NB) == 10)
 #endif
 
+// (Round 5: gpcc_potf2_core -- gpcc_kernels.hip.h, the same factorisation with its pivot-to-pivot chain taken off the lane broadcasts and
+// the LDS round trip -- halves the time of ONE wave alone on a SIMD (the tile kernels' diagonal steps, the persistent launch) and returns
+// the same bits; here, with two or three waves per SIMD filling each other's stalls, its extra broadcasts cost more issue slots than the
+// shorter chain saves: N = 110 33.8 M instead of 37.1 M evaluations/s, N = 150 15.9 M instead of 17.3 M, same box.  So this family keeps
+// the compact form.)
 __device__ __forceinline__ void gpcc_small_potf2(const double *sD, double *sX, double *sr, const int lane, const bool last,
                                                  const int base, double &py, int &pe, int &bad, double &quad)
 {
     constexpr int DLD = GPCC_SMALL_DLD;
     const int lr = lane & 15, q = lane >> 4;
-    double v[16];
+    double v[16], cn[16];
     const double *row = sD + ((q != 0 ? 16 : 0) + lr) * DLD;   // L lanes: row lr of D; X lanes: row lr of the identity
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) v[cc] = row[cc];
-    double rs_ = 0.0, rm_ = 0.0;
-    const int b16 = gpcc_potf2_core<true, false>(v, sr, lr, q, lane, last, py, pe, quad, sr, rs_, rm_);   // (gpcc_kernels.hip.h)
-    if (b16 && bad == 0) bad = base + b16;
+    for (int cc = 0; cc < 16; ++cc) { v[cc] = row[cc]; cn[cc] = 0.0; }
+    double d = gpcc_bcast(v[0], 0), vp = 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j == 15 && last) {   // the right-hand-side row: its Schur complement is -w'w; not a pivot
+            quad = -d;
+            d = 1.0;
+        }
+        if (!(d > 0.0) && bad == 0) bad = base + j + 1;   // also catches NaN
+        const double y = gpcc_rsqrt(d);
+        if (j >= 1) {   // the rest of pivot j-1's rank-1 update (column j had its share through the readlane below)
+#pragma unroll
+            for (int cc = j + 1; cc < 16; ++cc) v[cc] = __builtin_fma(-vp, cn[cc], v[cc]);
+        }
+        py *= __builtin_amdgcn_frexp_mant(y);
+        pe += __builtin_amdgcn_frexp_exp(y);
+        v[j] *= y;
+        if (j < 15) {
+            sr[q == 0 ? lr : 16 + lane] = v[j];   // column j of L_D -> LDS (the other lanes store to a dead area: no branch)
+            const double lnx = gpcc_bcast(v[j], j + 1);
+            v[j + 1] = __builtin_fma(-v[j], lnx, v[j + 1]);
+            d = gpcc_bcast(v[j + 1], j + 1);
+            vp = v[j];
+#pragma unroll
+            for (int cc = j + 2; cc < 16; ++cc) cn[cc] = sr[cc];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    pe += __builtin_amdgcn_frexp_exp(py);   // renormalise the running product once per block
+    py = __builtin_amdgcn_frexp_mant(py);
     if (q == 1) {   // -inv(L_D), row-major: sX[row cc][col l]
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc) sX[cc * DLD + lr] = -v[cc];
