@@ -152,6 +152,9 @@ def pmc_traffic(kernel, slots, N, prec="fp64"):
             d = json.load(f)
         if d.get("slots") != slots or d.get("N") != N:
             return None, None
+        import gpcc_amd
+        if d.get("build") != gpcc_amd.build_info():      # counters of another build of the library say nothing about this one
+            return None, "profiles/pmc_latest.json was recorded for build %r, this library is %r: re-run tools/profile_round.sh" % (d.get("build"), gpcc_amd.build_info())
         for name, e in d["kernels"].items():   # template instantiations carry their arguments in the name
             if name.startswith(kernel) and "hbm_bytes_per_launch" in e and ("<float" in name) == (prec == "fp32"):
                 return e["hbm_bytes_per_launch"], "profiles/pmc_latest.json: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % name
@@ -169,6 +172,130 @@ def delay_grid(L, Gtot):
     g1 = np.linspace(0.5, 6.0, side)
     d2, d3 = np.meshgrid(g1, g1, indexing="ij")
     return np.ascontiguousarray(np.stack([np.zeros(side * side), d2.ravel(), d3.ravel()], 1)[:Gtot])
+
+
+def roofline_leg(obj, args, N, L, G, Gtot, elapsed, run_once):
+    """The roofline object of the bench line: one more pass (`run_once`, profiled: HIP events around every launch on its own stream,
+    groups serialised) after the timed region.  Shared by both entries (device pointers under torch / one-process multi-device handle)."""
+    roofline = None
+    # dominant kernel = the fp64-MFMA panel update; its launches are timed live with HIP events
+    # on the stream they run on (gpcc_profile_*), groups serialised on one stream meanwhile.
+    obj.profile(True)
+    obj.profile_reset()
+    run_once()
+    prof = obj.profile_get()
+    obj.profile(False)
+    small = obj.get_option("small_n_active") == 1
+    slots = obj.get_option("workspace_slots")     # (= the option slots_per_stream unless the memory was short)
+    # the path a group takes: the fused step only for groups of >= fused_solve_min evaluations
+    # (gpcc_hip.hip: enqueue_factor_t); a ragged last group may take another path -- the dominant group decides
+    group = min(G, slots)
+    fused = (not small) and obj.get_option("fused_solve") == 1 and group >= obj.get_option("fused_solve_min") \
+        and group > obj.get_option("right_looking_max")
+    peak = FP64_MFMA_PEAK_TFLOPS if (args.precision == "fp64" or small) else FP32_MFMA_PEAK_TFLOPS
+    timing_note = ("separate profiled pass after the timed region: HIP events around every launch on its own stream, "
+                   "groups serialised on one stream (gpcc_profile_*); rocprofv3 --kernel-trace --stats of the same command: profiles/")
+    # profile slots -> the kernels that really ran in them on this path
+    if small:
+        wide = G <= obj.get_option("small_wide_max") or N > 191
+        names = {"small_eval": "gpcc_smallw_eval" if wide else "gpcc_small_eval"}
+    elif fused:
+        names = {"assemble": "gpcc_assemble_tiles", "panel_update": "gpcc_update_solve", "diag_factor": "gpcc_syrk_diag",
+                 "refine": "gpcc_back_solve+gpcc_refine_partials+gpcc_refine_finish"}
+    else:
+        names = {"assemble": "gpcc_assemble_tiles", "panel_update": "gpcc_panel_update", "diag_factor": "gpcc_diag_factor",
+                 "panel_trsm": "gpcc_panel_trsm(_rows)", "small_step": "gpcc_small_step",
+                 "refine": "gpcc_back_solve+gpcc_refine_partials+gpcc_refine_finish"}
+    kernels_ms = {names.get(k, k): round(v[1], 3) for k, v in prof.items() if v[0] > 0}
+    end_to_end = (N ** 3 / 3.0) * Gtot * args.steps / elapsed / 1e12     # SURVEY 8(d): N^3/3 per evaluation, whole step
+    n3 = N ** 3 / 3.0
+    executed = None
+    if small:
+        # ONE kernel does the whole evaluation (assembly + Cholesky + forward solve): algorithmic flops N^3/3 + N^2
+        launches, total_ms = prof["small_eval"]
+        kname = names["small_eval"]
+        flops_eval = N ** 3 / 3.0 + float(N) ** 2
+        executed = small_executed_ops(N, args.kernel)
+    else:
+        launches, total_ms = prof["panel_update"]
+        kname = names["panel_update"]
+        flops_eval, _ = update_flops_per_eval(N, fused)
+    if launches > 0 and total_ms > 0:
+        avg_ms = total_ms / launches
+        flops_per_launch = flops_eval * G / launches      # algorithmic flops / launch (average over steps k)
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        traffic, tsrc = pmc_traffic(kname, slots, N, args.precision)
+        roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 3),
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                    # the same launches credited with SURVEY 8(d)'s plain N^3/3 per evaluation (more than this kernel does when
+                    # the diagonal tiles run elsewhere): both accountings, so that neither has to be re-derived
+                    "frac_n3_over_3": round(n3 * G / launches / (avg_ms * 1e-3) / 1e12 / peak, 4),
+                    "frac_accounting": "frac: the flops THIS kernel performs (%s); frac_n3_over_3: N^3/3 per evaluation over the same launches"
+                                       % ("N^3/3 + N^2" if small else "dgemm + dtrsm of the tiles I > k" if fused else "dgemm tiles + dsyrk diagonal tile"),
+                    "traffic": traffic, "traffic_source": tsrc, "launches": launches, "avg_launch_ms": round(avg_ms, 4),
+                    "algorithmic_flops_per_launch": flops_per_launch, "timing": timing_note,
+                    "end_to_end_tflops": round(end_to_end, 3), "end_to_end_frac": round(end_to_end / peak, 4),
+                    "kernels_ms": kernels_ms}
+        if not small:   # the HBM-bound assembly kernel, reported beside it
+            an, ams = prof["assemble"]
+            nt = (N + TILE - 1) // TILE
+            esz = 8.0 if args.precision == "fp64" else 4.0
+            # fold_assembly (DESIGN.md 4.1c): the factorisation evaluates the off-diagonal tiles itself; what the assembly launches
+            # still write is the diagonal tiles (+ tile column 0 on the three-kernel path) and 4 N doubles of per-point factors
+            folded = (obj.get_option("fold_assembly") == 1 and nt > 1 and G > obj.get_option("fused_small_max")
+                      and (args.kernel != "rbf" or (args.precision == "fp32" and obj.get_option("fp32_assemble") == 1)))
+            tiles_written = (nt + (0 if fused else nt - 1)) if folded else nt * (nt + 1) / 2
+            abytes = (esz * TILE * TILE * tiles_written + (32.0 * N if folded else 0.0)) * G / max(an, 1)
+            roofline["assemble"] = {"bound": "hbm", "achieved": round(abytes / (ams / max(an, 1) * 1e-3) / 1e9, 1),
+                                    "peak": 8000.0, "unit": "GB/s", "avg_launch_ms": round(ams / max(an, 1), 4),
+                                    "algorithmic_bytes_per_launch": abytes, "folded_into_factorisation": bool(folded),
+                                    "tiles_written_per_evaluation": tiles_written,
+                                    "launches_counted": "gpcc_sep_points + gpcc_assemble_tiles" if folded else "gpcc_assemble_tiles"}
+        else:
+            # what the fp64 pipe EXECUTES per evaluation beside the algorithmic N^3/3 + N^2 (DESIGN.md 4.10): padded MFMA blocks,
+            # the element code (exp) and the 16 x 16 pivot steps, all on the same double-precision pipe
+            ex_total = sum(executed.values())
+            roofline["executed_ops"] = {"per_evaluation_dp_pipe_flops": {k: round(v) for k, v in executed.items()},
+                                        "total": round(ex_total), "algorithmic": round(flops_eval),
+                                        "executed_over_algorithmic": round(ex_total / flops_eval, 2),
+                                        "executed_tflops": round(ex_total * G / launches / (avg_ms * 1e-3) / 1e12, 2),
+                                        "executed_frac_of_peak": round(ex_total * G / launches / (avg_ms * 1e-3) / 1e12 / peak, 4)}
+            roofline["note"] = ("one wave (or four) per evaluation, matrix in registers: bound by VALU/MFMA issue of the fp64 pipe "
+                                "(assembly exp + 16x16 pivot chains + MFMAs), no HBM traffic beyond 3N inputs and 12 bytes out")
+    return roofline
+
+
+def cpu_baseline_leg(args, Nb, L, G, delays, ll_host):
+    """The cpu_baseline object of the bench line (rank 0, N = 1 only)."""
+    cpu_baseline = None
+    # Reported baseline, outside the timed region: the CPU shape of the reference's path -- scalar-loop assembly (the C
+    # restatement under oracle/) + OpenBLAS dpotrf/dtrtrs -- timed in its OWN process (it forks worker pools; this
+    # process holds the GPU) on a bounded sample of the same grid, both ways the README parallelises.
+    import subprocess
+    nsample = 8
+    idx = np.linspace(0, G - 1, nsample).astype(int)
+    cmd = [sys.executable, "-m", "oracle.lapack_baseline", "--n-per-band", str(Nb), "--bands", str(L), "--kernel", args.kernel,
+           "--seed", str(args.seed), "--delays", json.dumps(delays[idx].tolist()), "--evals-per-worker", str(args.cpu_sample or 24)]
+    c0 = time.perf_counter()
+    run = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
+    cpu_s = time.perf_counter() - c0
+    if run.returncode == 0:
+        rec = json.loads(run.stdout.strip().splitlines()[-1])
+        ref = np.array(rec["loglik"])
+        gpu_ll = np.asarray(ll_host)[idx][:len(ref)]
+        rel = float(np.max(np.abs(gpu_ll - ref) / np.abs(ref)))
+        best = rec["pmap"] if rec["pmap"]["evals_per_s"] >= rec["blas"]["evals_per_s"] else None
+        cpu_baseline = {"value": (best or rec["blas"])["evals_per_s"], "unit": "evals/s",
+                        "cores": best["workers"] if best else rec["blas"]["threads"], "kind": "port+LAPACK",
+                        "sample": "%d evaluations of the same grid (%d distinct delays), scalar-loop C assembly + OpenBLAS dpotrf/dtrtrs "
+                                  "(scipy), %s; reference not executable (no Julia)"
+                                  % ((best or rec["blas"])["evals"], nsample,
+                                     "P single-threaded worker processes (the README's pmap shape)" if best else "one evaluation at a time, BLAS on all threads"),
+                        "pmap_shape": rec["pmap_runs"], "blas_shape": rec["blas"], "cores_available": rec["cores_available"],
+                        "seconds": round(cpu_s, 2), "max_rel_err_gpu_vs_cpu": rel}
+    else:
+        cpu_baseline = {"value": None, "error": run.stderr[-400:]}
+    return cpu_baseline
 
 
 def native_multi(args, ndev):
@@ -211,6 +338,13 @@ def native_multi(args, ndev):
         gstate = smp.summary()
         mode = {1: "rccl", 2: "host"}.get(obj.get_option("gather_mode"), "?")
         comp_ms, gather_ms, total_ms = obj.multi_stats()     # of the LAST step: where a scaling loss would come from
+        roofline = cpu_baseline = None
+        if N_ == 1:     # a SCALE point at N = 1 through this entry is comparable with the BENCH line field by field
+            if not args.no_roofline:
+                roofline = roofline_leg(obj, args, L * Nb, L, G, Gtot, elapsed, lambda: obj.loglik_batch(delays, alphas, rhos))
+            if not args.no_cpu_baseline:
+                cpu_baseline = cpu_baseline_leg(args, Nb, L, G, delays, ll)
+        build = gpcc_amd.build_info()
     print(json.dumps({
         "metric": "delay-grid loglik evals/sec (N=%d, %d-band %s)" % (L * Nb, L, {"matern32": "Matern-3/2", "matern52": "Matern-5/2"}.get(args.kernel, args.kernel)),
         "value": round(Gtot * args.steps / elapsed, 2), "unit": "evals/s", "n_gpus": N_, "steps": args.steps, "warmup": args.warmup,
@@ -223,7 +357,8 @@ def native_multi(args, ndev):
         "last_step": {"per_device_compute_ms": [round(float(x), 3) for x in comp_ms], "gather_ms": round(gather_ms, 3),
                       "call_ms": round(total_ms, 3)},
         "clock_mhz": gstate["sclk_mhz"], "power_w": gstate["power_w"], "gpu_state": gstate,
-        "info_nonzero": int((info != 0).sum()), "posterior_sum": float(p.sum()), "roofline": None, "cpu_baseline": None}))
+        "info_nonzero": int((info != 0).sum()), "posterior_sum": float(p.sum()), "roofline": roofline, "cpu_baseline": cpu_baseline,
+        "entry": "native_multi", "build": build}))
 
 
 def main():
@@ -383,121 +518,14 @@ def main():
 
     roofline = None
     if rank == 0 and not args.no_roofline:
-        # dominant kernel = the fp64-MFMA panel update; its launches are timed live with HIP events
-        # on the stream they run on (gpcc_profile_*), groups serialised on one stream meanwhile.
-        obj.profile(True)
-        obj.profile_reset()
-        obj.loglik_batch_device(d_delays, d_alpha, d_rho, out=d_ll, info=d_info)
-        torch.cuda.synchronize(dev)
-        prof = obj.profile_get()
-        obj.profile(False)
-        small = obj.get_option("small_n_active") == 1
-        slots = obj.get_option("workspace_slots")     # (= the option slots_per_stream unless the memory was short)
-        # the path a group takes: the fused step only for groups of >= fused_solve_min evaluations
-        # (gpcc_hip.hip: enqueue_factor_t); a ragged last group may take another path -- the dominant group decides
-        group = min(G, slots)
-        fused = (not small) and obj.get_option("fused_solve") == 1 and group >= obj.get_option("fused_solve_min") \
-            and group > obj.get_option("right_looking_max")
-        peak = FP64_MFMA_PEAK_TFLOPS if (args.precision == "fp64" or small) else FP32_MFMA_PEAK_TFLOPS
-        timing_note = ("separate profiled pass after the timed region: HIP events around every launch on its own stream, "
-                       "groups serialised on one stream (gpcc_profile_*); rocprofv3 --kernel-trace --stats of the same command: profiles/")
-        # profile slots -> the kernels that really ran in them on this path
-        if small:
-            wide = G <= obj.get_option("small_wide_max") or N > 191
-            names = {"small_eval": "gpcc_smallw_eval" if wide else "gpcc_small_eval"}
-        elif fused:
-            names = {"assemble": "gpcc_assemble_tiles", "panel_update": "gpcc_update_solve", "diag_factor": "gpcc_syrk_diag",
-                     "refine": "gpcc_back_solve+gpcc_refine_partials+gpcc_refine_finish"}
-        else:
-            names = {"assemble": "gpcc_assemble_tiles", "panel_update": "gpcc_panel_update", "diag_factor": "gpcc_diag_factor",
-                     "panel_trsm": "gpcc_panel_trsm(_rows)", "small_step": "gpcc_small_step",
-                     "refine": "gpcc_back_solve+gpcc_refine_partials+gpcc_refine_finish"}
-        kernels_ms = {names.get(k, k): round(v[1], 3) for k, v in prof.items() if v[0] > 0}
-        end_to_end = (N ** 3 / 3.0) * Gtot * args.steps / elapsed / 1e12     # N^3/3 per evaluation, whole step
-        n3 = N ** 3 / 3.0
-        executed = None
-        if small:
-            # ONE kernel does the whole evaluation (assembly + Cholesky + forward solve): algorithmic flops N^3/3 + N^2
-            launches, total_ms = prof["small_eval"]
-            kname = names["small_eval"]
-            flops_eval = N ** 3 / 3.0 + float(N) ** 2
-            executed = small_executed_ops(N, args.kernel)
-        else:
-            launches, total_ms = prof["panel_update"]
-            kname = names["panel_update"]
-            flops_eval, _ = update_flops_per_eval(N, fused)
-        if launches > 0 and total_ms > 0:
-            avg_ms = total_ms / launches
-            flops_per_launch = flops_eval * G / launches      # algorithmic flops / launch (average over steps k)
-            achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            traffic, tsrc = pmc_traffic(kname, slots, N, args.precision)
-            roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 3),
-                        "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                        # the same launches credited with SURVEY 8(d)'s plain N^3/3 per evaluation (more than this kernel does when
-                        # the diagonal tiles run elsewhere): both accountings, so that neither has to be re-derived
-                        "frac_n3_over_3": round(n3 * G / launches / (avg_ms * 1e-3) / 1e12 / peak, 4),
-                        "frac_accounting": "frac: the flops THIS kernel performs (%s); frac_n3_over_3: N^3/3 per evaluation over the same launches"
-                                           % ("N^3/3 + N^2" if small else "dgemm + dtrsm of the tiles I > k" if fused else "dgemm tiles + dsyrk diagonal tile"),
-                        "traffic": traffic, "traffic_source": tsrc, "launches": launches, "avg_launch_ms": round(avg_ms, 4),
-                        "algorithmic_flops_per_launch": flops_per_launch, "timing": timing_note,
-                        "end_to_end_tflops": round(end_to_end, 3), "end_to_end_frac": round(end_to_end / peak, 4),
-                        "kernels_ms": kernels_ms}
-            if not small:   # the HBM-bound assembly kernel, reported beside it
-                an, ams = prof["assemble"]
-                nt = (N + TILE - 1) // TILE
-                esz = 8.0 if args.precision == "fp64" else 4.0
-                # fold_assembly: the factorisation evaluates the off-diagonal tiles itself; what the assembly launches
-                # still write is the diagonal tiles (+ tile column 0 on the three-kernel path) and 4 N doubles of per-point factors
-                folded = (obj.get_option("fold_assembly") == 1 and nt > 1 and G > obj.get_option("fused_small_max")
-                          and (args.kernel != "rbf" or (args.precision == "fp32" and obj.get_option("fp32_assemble") == 1)))
-                tiles_written = (nt + (0 if fused else nt - 1)) if folded else nt * (nt + 1) / 2
-                abytes = (esz * TILE * TILE * tiles_written + (32.0 * N if folded else 0.0)) * G / max(an, 1)
-                roofline["assemble"] = {"bound": "hbm", "achieved": round(abytes / (ams / max(an, 1) * 1e-3) / 1e9, 1),
-                                        "peak": 8000.0, "unit": "GB/s", "avg_launch_ms": round(ams / max(an, 1), 4),
-                                        "algorithmic_bytes_per_launch": abytes, "folded_into_factorisation": bool(folded),
-                                        "tiles_written_per_evaluation": tiles_written,
-                                        "launches_counted": "gpcc_sep_points + gpcc_assemble_tiles" if folded else "gpcc_assemble_tiles"}
-            else:
-                # what the fp64 pipe EXECUTES per evaluation beside the algorithmic N^3/3 + N^2: padded MFMA blocks,
-                # the element code (exp) and the 16 x 16 pivot steps, all on the same double-precision pipe
-                ex_total = sum(executed.values())
-                roofline["executed_ops"] = {"per_evaluation_dp_pipe_flops": {k: round(v) for k, v in executed.items()},
-                                            "total": round(ex_total), "algorithmic": round(flops_eval),
-                                            "executed_over_algorithmic": round(ex_total / flops_eval, 2),
-                                            "executed_tflops": round(ex_total * G / launches / (avg_ms * 1e-3) / 1e12, 2),
-                                            "executed_frac_of_peak": round(ex_total * G / launches / (avg_ms * 1e-3) / 1e12 / peak, 4)}
-                roofline["note"] = ("one wave (or four) per evaluation, matrix in registers: bound by VALU/MFMA issue of the fp64 pipe "
-                                    "(assembly exp + 16x16 pivot chains + MFMAs), no HBM traffic beyond 3N inputs and 12 bytes out")
+        def run_once():
+            obj.loglik_batch_device(d_delays, d_alpha, d_rho, out=d_ll, info=d_info)
+            torch.cuda.synchronize(dev)
+        roofline = roofline_leg(obj, args, N, L, G, Gtot, elapsed, run_once)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # Reported baseline, outside the timed region: the CPU shape of the reference's path -- scalar-loop assembly (the C
-        # restatement under oracle/) + OpenBLAS dpotrf/dtrtrs -- timed in its OWN process (it forks worker pools; this
-        # process holds the GPU) on a bounded sample of the same grid, both ways the README parallelises.
-        import subprocess
-        nsample = 8
-        idx = np.linspace(0, G - 1, nsample).astype(int)
-        cmd = [sys.executable, "-m", "oracle.lapack_baseline", "--n-per-band", str(Nb), "--bands", str(L), "--kernel", args.kernel,
-               "--seed", str(args.seed), "--delays", json.dumps(delays[idx].tolist()), "--evals-per-worker", str(args.cpu_sample or 24)]
-        c0 = time.perf_counter()
-        run = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
-        cpu_s = time.perf_counter() - c0
-        if run.returncode == 0:
-            rec = json.loads(run.stdout.strip().splitlines()[-1])
-            ref = np.array(rec["loglik"])
-            gpu_ll = d_ll.cpu().numpy()[idx][:len(ref)]
-            rel = float(np.max(np.abs(gpu_ll - ref) / np.abs(ref)))
-            best = rec["pmap"] if rec["pmap"]["evals_per_s"] >= rec["blas"]["evals_per_s"] else None
-            cpu_baseline = {"value": (best or rec["blas"])["evals_per_s"], "unit": "evals/s",
-                            "cores": best["workers"] if best else rec["blas"]["threads"], "kind": "port+LAPACK",
-                            "sample": "%d evaluations of the same grid (%d distinct delays), scalar-loop C assembly + OpenBLAS dpotrf/dtrtrs "
-                                      "(scipy), %s; reference not executable (no Julia)"
-                                      % ((best or rec["blas"])["evals"], nsample,
-                                         "P single-threaded worker processes (the README's pmap shape)" if best else "one evaluation at a time, BLAS on all threads"),
-                            "pmap_shape": rec["pmap_runs"], "blas_shape": rec["blas"], "cores_available": rec["cores_available"],
-                            "seconds": round(cpu_s, 2), "max_rel_err_gpu_vs_cpu": rel}
-        else:
-            cpu_baseline = {"value": None, "error": run.stderr[-400:]}
+        cpu_baseline = cpu_baseline_leg(args, Nb, L, G, delays, d_ll.cpu().numpy())
 
     if rank == 0:
         out = {
@@ -514,6 +542,7 @@ def main():
             "clock_mhz": gstate["sclk_mhz"], "power_w": gstate["power_w"], "gpu_state": gstate,
             "info_nonzero": info_bad, "posterior_sum": psum,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "shared_prefix_mode": shared,
+            "entry": "device_pointer", "build": gpcc_amd.build_info(),
         }
         print(json.dumps(out))
     obj.close()

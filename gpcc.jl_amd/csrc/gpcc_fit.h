@@ -343,4 +343,50 @@ struct BatchedNelderMead {
     }
 };
 
+// ------------------------------------------------------------------------------------------
+// The deal of a delay grid over the devices of a multi-device handle (multi_grid_loglik, gpcc_hip.hip): device i fits the delays i,
+// i + n, i + 2 n, ... (round-robin: iteration counts differ from delay to delay); its results travel as a block of `blk` =
+// ceil(G / n) rows [loglik | info | iterations | rho | alpha(L)] (padding rows: NaN, 0, ...), the n blocks are gathered, and the
+// caller's arrays are filled from the gathered buffer.  Pure index arithmetic, kept here so that the CPU suite pins it
+// (tests/abi/fit_host_sanitize.cpp: G not divisible by n, G < n, G = 0).
+// ------------------------------------------------------------------------------------------
+inline long deal_count(long G, int n, int i) { return (G > i) ? (G - i + n - 1) / n : 0; }   // delays of device i
+inline long deal_global(int n, int i, long j) { return j * n + i; }                          // grid index of device i's j-th delay
+inline void deal_pack_rows(long blk, int L, long Gi, const double *ll, const int *info, const int *its, const double *rho, const double *alpha,
+                           double *row /* blk x (L + 4) */)
+{
+    const int W = L + 4;
+    for (long j = 0; j < blk; ++j) {
+        double *q = row + (size_t)j * W;
+        for (int e = 0; e < W; ++e) q[e] = 0.0;
+        if (j < Gi) {
+            q[0] = ll[j];
+            q[1] = (double)info[j];
+            q[2] = (double)its[j];
+            q[3] = rho[j];
+            for (int l = 0; l < L; ++l) q[4 + l] = alpha[(size_t)j * L + l];
+        } else {
+            q[0] = std::numeric_limits<double>::quiet_NaN();
+        }
+    }
+}
+inline void deal_scatter(long G, int n, int L, long blk, const double *gathered /* n x blk x (L + 4) */, double *loglik_out, int *info_out,
+                         int *iterations_out /* may be NULL */, double *rho_out, double *alpha_out)
+{
+    const int W = L + 4;
+    for (int i = 0; i < n; ++i) {
+        const long Gi = deal_count(G, n, i);
+        const double *src = gathered + (size_t)i * blk * W;
+        for (long j = 0; j < Gi; ++j) {
+            const long g = deal_global(n, i, j);
+            const double *q = src + (size_t)j * W;
+            loglik_out[g] = q[0];
+            info_out[g] = (int)q[1];
+            if (iterations_out) iterations_out[g] = (int)q[2];
+            rho_out[g] = q[3];
+            for (int l = 0; l < L; ++l) alpha_out[(size_t)g * L + l] = q[4 + l];
+        }
+    }
+}
+
 }   // namespace gpccfit

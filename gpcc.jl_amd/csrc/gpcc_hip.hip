@@ -2283,9 +2283,9 @@ static int multi_grid_loglik(gpcc_handle_t h, int G, const double *delays, int i
     std::vector<int> rcs(n, 0);
     for (int i = 0; i < n; ++i) {
         Share &s = sh[i];
-        const long Gi = (G > i) ? ((long)G - i + n - 1) / n : 0;
+        const long Gi = gpccfit::deal_count(G, n, i);
         s.delays.resize((size_t)Gi * L); s.ll.resize(Gi); s.alpha.resize((size_t)Gi * L); s.rho.resize(Gi); s.info.resize(Gi); s.its.resize(Gi);
-        for (long j = 0; j < Gi; ++j) memcpy(&s.delays[(size_t)j * L], delays + ((size_t)j * n + i) * L, sizeof(double) * L);
+        for (long j = 0; j < Gi; ++j) memcpy(&s.delays[(size_t)j * L], delays + (size_t)gpccfit::deal_global(n, i, j) * L, sizeof(double) * L);
         auto job = [h, i, Gi, iterations, R, C, rhomin, rhomax, cands, blk, W, L, &sh]() -> int {
             Share &s = sh[i];
             gpcc_handle_t sub = h->subs[i];
@@ -2297,15 +2297,7 @@ static int multi_grid_loglik(gpcc_handle_t h, int G, const double *delays, int i
             s.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             // this device's block of the gather: rows [loglik | info | iterations | rho | alpha(L)], padding NaN / 0
             s.row.assign((size_t)blk * W, 0.0);
-            for (long j = 0; j < blk; ++j) {
-                double *q = &s.row[(size_t)j * W];
-                if (j < Gi) {
-                    q[0] = s.ll[j]; q[1] = (double)s.info[j]; q[2] = (double)s.its[j]; q[3] = s.rho[j];
-                    for (int l = 0; l < L; ++l) q[4 + l] = s.alpha[(size_t)j * L + l];
-                } else {
-                    q[0] = std::numeric_limits<double>::quiet_NaN();
-                }
-            }
+            gpccfit::deal_pack_rows(blk, L, Gi, s.ll.data(), s.info.data(), s.its.data(), s.rho.data(), s.alpha.data(), s.row.data());
             GPCC_ON_DEVICE(sub, sub->device);
             HIPCHK(sub, hipMemcpyAsync(h->d_send[i], s.row.data(), sizeof(double) * blk * W, hipMemcpyHostToDevice, sub->main_stream));
             if (h->gather_mode == GPCC_GATHER_HOST) memcpy(h->h_gather.data() + (size_t)i * blk * W, s.row.data(), sizeof(double) * blk * W);
@@ -2347,18 +2339,8 @@ static int multi_grid_loglik(gpcc_handle_t h, int G, const double *delays, int i
         }
     }
     long long f_calls = 0, rounds = 0;
+    gpccfit::deal_scatter(G, n, L, blk, h->h_gather.data(), loglik_out, info_out, iterations_out, rho_out, alpha_out);
     for (int i = 0; i < n; ++i) {
-        const long Gi = (G > i) ? ((long)G - i + n - 1) / n : 0;
-        const double *src = h->h_gather.data() + (size_t)i * blk * W;
-        for (long j = 0; j < Gi; ++j) {
-            const long g = j * n + i;
-            const double *q = src + (size_t)j * W;
-            loglik_out[g] = q[0];
-            info_out[g] = (int)q[1];
-            if (iterations_out) iterations_out[g] = (int)q[2];
-            rho_out[g] = q[3];
-            for (int l = 0; l < L; ++l) alpha_out[(size_t)g * L + l] = q[4 + l];
-        }
         f_calls += sh[i].stats[0];
         rounds = std::max(rounds, sh[i].stats[1]);   // the devices advance side by side
         h->stat_compute_ms[i] = sh[i].ms;            // (host wall clock of the device's whole fit)

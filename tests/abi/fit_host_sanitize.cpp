@@ -76,5 +76,45 @@ int main()
         }
         std::printf("initial_params: ok\n");
     }
+    {   // the round-robin deal of a grid over n devices and its reassembly from the gathered blocks (multi_grid_loglik): every grid
+        // point comes back exactly once, in its own slot, with its own values -- G not divisible by n, G < n, G = 0, one device
+        long cases = 0;
+        for (int L = 1; L <= 3; ++L)
+            for (int n = 1; n <= 5; ++n)
+                for (long G = 0; G <= 17; ++G) {
+                    const int W = L + 4;
+                    const long blk = (G + n - 1) / n;
+                    std::vector<double> gathered((size_t)n * (blk > 0 ? blk : 1) * W, -777.0);
+                    long total = 0;
+                    for (int i = 0; i < n; ++i) {
+                        const long Gi = gpccfit::deal_count(G, n, i);
+                        total += Gi;
+                        if (Gi > blk) return 11;
+                        std::vector<double> ll(Gi), rho(Gi), alpha((size_t)Gi * L);
+                        std::vector<int> info(Gi), its(Gi);
+                        for (long j = 0; j < Gi; ++j) {
+                            const long g = gpccfit::deal_global(n, i, j);
+                            if (g < 0 || g >= G) return 12;
+                            ll[j] = -1000.0 - g; info[j] = (int)(g % 3); its[j] = (int)(100 + g); rho[j] = 0.5 + g;
+                            for (int l = 0; l < L; ++l) alpha[(size_t)j * L + l] = 10.0 * g + l;
+                        }
+                        gpccfit::deal_pack_rows(blk, L, Gi, ll.data(), info.data(), its.data(), rho.data(), alpha.data(), gathered.data() + (size_t)i * blk * W);
+                        for (long j = Gi; j < blk; ++j)
+                            if (!std::isnan(gathered[((size_t)i * blk + j) * W])) return 13;   // padding rows are marked
+                    }
+                    if (total != G) return 14;
+                    std::vector<double> lo(G + 1, 7.0), ro(G + 1, 7.0), ao((size_t)(G + 1) * L, 7.0);
+                    std::vector<int> io(G + 1, 7), to(G + 1, 7);
+                    gpccfit::deal_scatter(G, n, L, blk, gathered.data(), lo.data(), io.data(), to.data(), ro.data(), ao.data());
+                    for (long g = 0; g < G; ++g) {
+                        if (lo[g] != -1000.0 - g || io[g] != (int)(g % 3) || to[g] != (int)(100 + g) || ro[g] != 0.5 + g) return 15;
+                        for (int l = 0; l < L; ++l)
+                            if (ao[(size_t)g * L + l] != 10.0 * g + l) return 16;
+                    }
+                    if (lo[G] != 7.0 || io[G] != 7 || ao[(size_t)G * L] != 7.0) return 17;   // nothing written past the grid
+                    ++cases;
+                }
+        std::printf("round-robin deal: %ld cases ok\n", cases);
+    }
     return 0;
 }

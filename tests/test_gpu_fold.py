@@ -166,3 +166,22 @@ def test_folded_fp32_tiles_return_the_bits_of_assembled_tiles(gp, oracle, kname,
     ref, rinfo = oracle.loglik_batch(kname, t, y, s, delays, alphas, rhos, mb, nthreads=8)
     assert np.array_equal(rinfo == 0, ok)
     assert _rel(a[ok], ref[ok]) <= 1e-3
+
+
+def test_dense_export_at_headline_size_assembles_every_tile(gp, oracle):
+    """gpcc_model_matrix at N = 4096 (2 x 2048: 496 off-diagonal tiles inside one band pair, the ones a folded factorisation would
+    leave unwritten) after a folded batch on the same handle: every tile of the dense export is assembled (gpcc_assemble_tiles writes
+    the whole lower triangle: the fold must never leak into the dense export) -- every element against the oracle's delayedCovariance
+    + Sobs + B (marginaliseb.jl:135), exactly symmetric, no element left at zero."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([2048, 2048], seed=1)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    with gp.Objective(t, y, s, "matern32", slots_per_stream=32) as obj:
+        M = 32
+        d = np.stack([np.zeros(M), np.linspace(0, 20, M)], 1)
+        obj.loglik_batch(d, np.tile(alpha, (M, 1)), np.full(M, rho))     # a folded group first (left-looking, fused halves)
+        K = obj.model_matrix([0.0, 2.5], alpha, rho)
+    assert K.shape == (4096, 4096) and np.array_equal(K, K.T)
+    Kref, _ = oracle.model_matrix("matern32", t, y, s, [0.0, 2.5], alpha, rho, True)
+    np.testing.assert_allclose(K, Kref, rtol=1e-13, atol=1e-300)
+    assert not np.any(K == 0.0)     # (an unwritten tile would read as the zeros of a fresh allocation, or as stale factor data)

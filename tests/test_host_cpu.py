@@ -87,6 +87,7 @@ def test_native_optimiser_under_sanitizers(tmp_path):
     assert run.returncode == 0, run.stdout + run.stderr[-3000:]
     assert "rosenbrock" in run.stdout and "bowl5: ok" in run.stdout and "initial_params: ok" in run.stdout
     assert "speculative rounds:" in run.stdout      # bitwise the plain trajectories, fewer rounds (checked inside)
+    assert "round-robin deal:" in run.stdout        # the grid's deal over n devices and its reassembly: G % n != 0, G < n, G = 0
 
 
 def test_julia_shim_file_matches_integration_md_and_the_header():

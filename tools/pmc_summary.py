@@ -12,6 +12,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from gpcc_amd.build import build_info_string  # noqa: E402  (the library the counters were taken on: bench.py quotes them only for the same build)
+
 
 def short(name):
     return name.split("(")[0].replace("void ", "").strip()
@@ -37,7 +40,7 @@ def main():
     # N / slots: the configuration the passes ran (bench.py's defaults) -- bench.py only quotes `traffic` from a summary that matches
     out = {"note": "PMC passes: one 256-evaluation group (bench.py --grid 256 --steps 1 --warmup 0); "
                    "stats: default bench command", "N": int(os.environ.get("GPCC_PMC_N", "4096")),
-           "slots": int(os.environ.get("GPCC_PMC_SLOTS", "256")), "source": "tools/profile_round.sh -> tools/pmc_summary.py %s" % d,
+           "slots": int(os.environ.get("GPCC_PMC_SLOTS", "256")), "build": build_info_string(), "source": "tools/profile_round.sh -> tools/pmc_summary.py %s" % d,
            "kernels": {}}
     stats = glob.glob("%s/stats/*/*_kernel_stats.csv" % d)
     if stats:
