@@ -56,8 +56,9 @@ typedef unsigned gpcc_u4 __attribute__((ext_vector_type(4)));
 #endif
 
 struct GpccChainArgs {
-    unsigned *words;             // zeroed before every launch: [0] abort word; [16 + k] job counter of step k; then per evaluation (ev_words each):
-                                 //   xrow[nt] | colflag[nt][8] | lcnt[ntiles] | ver[ntiles]
+    unsigned *words;             // zeroed before every launch: [0] abort word; [16 + k] job counter of step k (k = 0 .. nt - 1); from qbase on, per
+                                 // evaluation (ev_words each):
+                                 //   xrow[nt] | d7[nt] | colflag[nt][8] | lcnt[ntiles] | ver[ntiles]
     double *ximg;                // evaluations x nt x GPCC_XIMG_ELEMS: inv(L_kk) as published (block (f, ch) at gpcc_bi(f, ch), [row][col] row-major)
     double *stepval;             // evaluations x nt x GPCC_CHAIN_STEPVALS: per diagonal step [sum log L_ii of the block, first bad pivot, W'W]
     unsigned long long *trace;   // optional (NULL): evaluations x nt x GPCC_CHAIN_TRACE_WORDS wall-clock stamps of the chain (tools/chain_trace.py)
@@ -65,6 +66,8 @@ struct GpccChainArgs {
     int wtrace_cap;
     int ev_words;                // words per evaluation
     int qbase;                   // first per-evaluation word
+    int helpers;                 // 1: four more dedicated workgroups per evaluation run the quarter solves of the tile below the diagonal
+                                 //    (few evaluations: latency); 0: those solves are queue jobs like the others (more workers)
 };
 
 // ---- agent-scope accesses (all hand-off traffic): relaxed atomics lower to global_load / global_store ... sc1
@@ -124,7 +127,7 @@ __device__ __forceinline__ bool gpcc_wait_ge(const unsigned *p, unsigned want, u
 __device__ __forceinline__ int gpcc_tile_idx(int I, int J) { return I * (I + 1) / 2 + J; }
 // the flag words of evaluation m
 struct GpccChainFlags {
-    unsigned *abortw, *xrow, *colflag, *lcnt, *ver;
+    unsigned *abortw, *xrow, *d7, *colflag, *lcnt, *ver;
 };
 __device__ __forceinline__ GpccChainFlags gpcc_chain_flags(const GpccChainArgs &a, int nt, int m)
 {
@@ -133,9 +136,10 @@ __device__ __forceinline__ GpccChainFlags gpcc_chain_flags(const GpccChainArgs &
     const int ntiles = nt * (nt + 1) / 2;
     f.abortw = a.words;
     f.xrow = ev;
-    f.colflag = ev + nt;
-    f.lcnt = ev + 9 * nt;
-    f.ver = ev + 9 * nt + ntiles;
+    f.d7 = ev + nt;
+    f.colflag = ev + 2 * nt;
+    f.lcnt = ev + 10 * nt;
+    f.ver = ev + 10 * nt + ntiles;
     return f;
 }
 
@@ -204,7 +208,7 @@ GPCC_CHAIN_FN void gpcc_chain_diag(const GpccCtx &c, const GpccGroup &g, const G
         GPCC_OPAQUE_LANE(lrv, qv);
         d4 xo[2];            // rows of inv(L) built in this round: written after the barrier (in place of L's row)
         int xj[2] = {-1, -1};
-        if (wave == 4 && jb == 0) {
+        if (wave == 6 && jb == 0) {
             // z_k: the right-hand side of this step's forward substitution.  Its last update -- z_k -= L(k,k-1) w_{k-1} -- is the END of the
             // four quarter solves of tile (k,k-1) (lcnt = 4), a hand-off later than the last column block this workgroup has just folded
             // in; it is first read by the W task of block step 1, two barriers from here: loaded now, beside the first 16 pivots
@@ -214,7 +218,14 @@ GPCC_CHAIN_FN void gpcc_chain_diag(const GpccCtx &c, const GpccGroup &g, const G
             for (int e = lane; e < nrhs * GPCC_TILE; e += 64)
                 sz[e] = gpcc_ld_sc1(c.z + ((long)slot * nrhs + e / GPCC_TILE) * c.Np + k * GPCC_TILE + (e % GPCC_TILE));
         }
-        if (wave == 4 && jb >= 2) {   // row block jb - 2 of inv(L) is final: out it goes (nothing of it is written any more)
+        if (wave == 6 && jb >= 2) {   // row block jb - 2 of inv(L) is final: out it goes (nothing of it is written any more)
+            // (wave 6 -- a worker with time to spare: wave 4, which has nothing else to do, shares wave 0's SIMD, and whatever it issues
+            //  there is taken from the pivot chain's issue slots)
+            // The LAST row block of inv(L) is never built: a solve finishes its last column block by forward substitution from row
+            // block 7 of L itself (final since the panel of column block 6: out now, with row block 5 of the inverse) and inv(D_7) (out
+            // right behind the last 16 pivots, below: d7)
+            if (jb == 7)
+                for (int j = 0; j <= 6; ++j) gpcc_chain_publish_block(sB, xr, 7, j, lane);
             for (int j = 0; j <= jb - 2; ++j) gpcc_chain_publish_block(sB, xr, jb - 2, j, lane);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) gpcc_flag_st(&fl.xrow[k], (unsigned)(jb - 1));
@@ -321,8 +332,7 @@ GPCC_CHAIN_FN void gpcc_chain_diag(const GpccCtx &c, const GpccGroup &g, const G
             bool dow = false;
             int j0 = -1, j1 = -1;
             if (jb == 8) {
-                dow = wave == 0;
-                j0 = wave - 1;
+                dow = wave == 0;     // (W only: the last row block of the inverse is not needed, see above)
             } else if (wk >= 0) {
                 dow = wk == 0;
                 j0 = wk - 1;
@@ -392,6 +402,12 @@ GPCC_CHAIN_FN void gpcc_chain_diag(const GpccCtx &c, const GpccGroup &g, const G
         if (trd && tid == 0) trd[8 * jb + 1] = wall_clock64();
         __syncthreads();   // every reader of L's row jb-1 is done
         if (trd && tid == 0) trd[8 * jb + 2] = wall_clock64();
+        if (jb == 7 && wave == 6) {   // inv(D_7) is in the image: out at once, with a flag of its own -- the solves' last column block waits for it
+            gpcc_chain_publish_block(sB, xr, 7, 7, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) gpcc_flag_st(&fl.d7[k], 1u);
+            if (trd && lane == 0) trd[-5] = wall_clock64();   // (header word 3)
+        }
         GPCC_OPAQUE_LANE(lrv, qv);
         if (jb > 0) {
             const int i = jb - 1;
@@ -422,9 +438,7 @@ GPCC_CHAIN_FN void gpcc_chain_diag(const GpccCtx &c, const GpccGroup &g, const G
         if (trd && tid == 0) trd[8 * jb + 3] = wall_clock64();
     }
     __syncthreads();   // row block 7 of inv(L) is in the image, sz holds W_k
-    // ---- the end of the step goes out together: row block 7 of inv(L) (one block per wave), W_k, the step's scalars -- then ONE flag
-    // value says "all of step k is there"
-    gpcc_chain_publish_block(sB, xr, 7, wave, lane);
+    // ---- the end of the step: W_k and the step's scalars -- then ONE flag value says "all of step k is there"
     for (int e = tid; e < nrhs * GPCC_TILE; e += NT)
         gpcc_st_sc1(c.w + ((long)slot * nrhs + e / GPCC_TILE) * c.Np + k * GPCC_TILE + (e % GPCC_TILE), sz[e]);
     double *sv = a.stepval + ((long)m * c.nt + k) * GPCC_CHAIN_STEPVALS;
@@ -479,7 +493,7 @@ GPCC_CHAIN_FN void gpcc_chain_diag(const GpccCtx &c, const GpccGroup &g, const G
 // ------------------------------------------------------------------------------------------
 template <int RA, int CA, int NA, int RB, int CB, int NB>
 GPCC_CHAIN_FN bool gpcc_chain_syrk_wave(const double *Tt, const double *Lt, const unsigned *colflag, unsigned *abortw, double *smem, int *ctl,
-                                                     int tid, int lane)
+                                                     int tid, int lane, unsigned long long *tr)
 {
     typedef GpccPrec<double> P;
     const int lr = lane & 15, q = lane >> 4, sw = gpcc_sw(lr);
@@ -501,6 +515,7 @@ GPCC_CHAIN_FN bool gpcc_chain_syrk_wave(const double *Tt, const double *Lt, cons
         int okw = 1;
         if (lane == 0) okw = gpcc_wait_ge(&colflag[ch], 4u, abortw, 0x100u + ch) ? 1 : 0;
         okw = __builtin_amdgcn_readfirstlane(okw);
+        if (tr && ch == 7 && tid == 0) tr[7] = wall_clock64();   // header word 7: the last column block of L(k,k-1) seen
         const int so = (ch & 1) * 2048;
         if (okw) gpcc_dma_piece2_sc1(gpcc_uniform_ptr(Lt + ch * 2048 + wave * 256), (unsigned)lane * 16u, smem_addr + (unsigned)(so * 8 + wave * 2048));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -573,14 +588,14 @@ __device__ __forceinline__ void gpcc_chain_role(const GpccCtx &c, const GpccGrou
             const unsigned *cf = fl.colflag + 8 * (k - 1);
             bool ok;
             switch (wave) {
-            case 0: ok = gpcc_chain_syrk_wave<7, 0, 5, 0, 0, 0>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane); break;
-            case 1: ok = gpcc_chain_syrk_wave<6, 0, 5, 0, 0, 0>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane); break;
-            case 2: ok = gpcc_chain_syrk_wave<5, 0, 5, 0, 0, 0>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane); break;
-            case 3: ok = gpcc_chain_syrk_wave<4, 0, 5, 0, 0, 0>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane); break;
-            case 4: ok = gpcc_chain_syrk_wave<7, 5, 3, 0, 0, 1>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane); break;
-            case 5: ok = gpcc_chain_syrk_wave<6, 5, 2, 1, 0, 2>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane); break;
-            case 6: ok = gpcc_chain_syrk_wave<5, 5, 1, 2, 0, 3>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane); break;
-            default: ok = gpcc_chain_syrk_wave<3, 0, 4, 0, 0, 0>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane); break;
+            case 0: ok = gpcc_chain_syrk_wave<7, 0, 5, 0, 0, 0>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane, tr); break;
+            case 1: ok = gpcc_chain_syrk_wave<6, 0, 5, 0, 0, 0>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane, tr); break;
+            case 2: ok = gpcc_chain_syrk_wave<5, 0, 5, 0, 0, 0>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane, tr); break;
+            case 3: ok = gpcc_chain_syrk_wave<4, 0, 5, 0, 0, 0>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane, tr); break;
+            case 4: ok = gpcc_chain_syrk_wave<7, 5, 3, 0, 0, 1>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane, tr); break;
+            case 5: ok = gpcc_chain_syrk_wave<6, 5, 2, 1, 0, 2>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane, tr); break;
+            case 6: ok = gpcc_chain_syrk_wave<5, 5, 1, 2, 0, 3>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane, tr); break;
+            default: ok = gpcc_chain_syrk_wave<3, 0, 4, 0, 0, 0>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane, tr); break;
             }
             if (!ok) return;
         }
@@ -644,9 +659,24 @@ GPCC_CHAIN_FN bool gpcc_chain_trsmq(const GpccCtx &c, const GpccChainArgs &a, co
             }
         }
     };
+    // The quarter's own results, row-major 16 x 16 per (column block, row half): the LAST column block is solved from them
+    double *lbuf = smem + 4096;            // [7][2][256]
+    double *sbuf = lbuf + 7 * 2 * 256;     // [2][256]: T_7 - sum_j Lnew_j Lkk[7][j]^T, then the finished block
+    const d2 t7 = (tid < 256) ? gpcc_ld16_sc1(tres, (unsigned)((7 * 2048 + (32 * qr + 16 * rh2 + rrow) * 16 + ((sp ^ gpcc_sw(32 * qr + 16 * rh2 + rrow)) * 2)) * 8))
+                              : d2{0.0, 0.0};   // this reducer's two elements of column block 7 of T(I,k)
+    // column block f of L(I,k), published the moment its four storing waves have drained: each adds to an LDS counter behind its own
+    // wait, the last one adds to the global counter the chain polls (no workgroup barrier in between)
+    auto signal_block = [&](int f) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int last = 0;
+        if (lane == 0) last = (__hip_atomic_fetch_add(&cdone[f], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 3) ? 1 : 0;
+        if (last) gpcc_flag_add(&fl.colflag[8 * k + f], 1u);
+    };
+    d2 b7[2][2] = {{{0.0, 0.0}, {0.0, 0.0}}, {{0.0, 0.0}, {0.0, 0.0}}};
+    unsigned long long *ht = (a.trace && chain_tile) ? a.trace + ((long)m * c.nt + k) * GPCC_CHAIN_TRACE_WORDS : nullptr;   // header words 4-6 of step k: the LAST of the four quarters of tile (k+1,k) (atomic max)
 #pragma unroll
-    for (int f = 0; f < 8; ++f) {   // (unrolled: lv stays in registers)
-        const int need = (f < 7) ? f + 1 : 9;
+    for (int f = 0; f < 7; ++f) {   // (unrolled: lv stays in registers)
+        const int need = f + 1;
         if (seen < need) {          // caught up with the diagonal step: wait for its next row block (one lane polls; wave 7 is not a reducer)
             if (tid == GPCC_CHAIN_THREADS - 64) {
                 ctl[0] = gpcc_wait_ge(&fl.xrow[k], (unsigned)need, fl.abortw, 0x310u + f) ? 1 : 0;
@@ -657,6 +687,17 @@ GPCC_CHAIN_FN bool gpcc_chain_trsmq(const GpccCtx &c, const GpccChainArgs &a, co
             seen = ctl[3];
             __syncthreads();        // (ctl[3] is rewritten below)
         }
+        if (f == 6) {   // row block 7 of L_kk went out before xrow = 6: fetched here, a column block ahead of its use below
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const int j = kq + 4 * c2;
+                if (j < 7) {
+                    const unsigned off = (unsigned)((gpcc_bi(7, j) + lr * 16 + 4 * q) * 8);
+                    b7[c2][0] = gpcc_ld16_sc1(xres, off);
+                    b7[c2][1] = gpcc_ld16_sc1(xres, off + 16u);
+                }
+            }
+        }
         d2 b[2][2];
         if (have_next) {
 #pragma unroll
@@ -664,7 +705,7 @@ GPCC_CHAIN_FN bool gpcc_chain_trsmq(const GpccCtx &c, const GpccChainArgs &a, co
         } else {
             load_b(f, b);
         }
-        have_next = (f < 7) && (seen >= ((f + 1 < 7) ? f + 2 : 9));
+        have_next = (f < 6) && (seen >= f + 2);
         if (have_next) load_b(f + 1, bn);
         d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -691,21 +732,83 @@ GPCC_CHAIN_FN bool gpcc_chain_trsmq(const GpccCtx &c, const GpccChainArgs &a, co
             sm += *(const d2 *)(pp + 6 * 256);
             lv[f][0] = sm[0];
             lv[f][1] = sm[1];
+            *(d2 *)(lbuf + (f * 2 + rh2) * 256 + rrow * 16 + 2 * sp) = sm;
             const int row = 32 * qr + 16 * rh2 + rrow;
             gpcc_st16_sc1(tres, (unsigned)((f * 2048 + row * 16 + ((sp ^ gpcc_sw(row)) * 2)) * 8), sm);
-            if (chain_tile) {
-                // column block f of L(k+1,k) is signalled the moment its four storing waves have drained: each adds to an LDS counter
-                // behind its own wait, the last one adds to the global counter the chain polls (no workgroup barrier in between)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                int last = 0;
-                if (lane == 0) last = (__hip_atomic_fetch_add(&cdone[f], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 3) ? 1 : 0;
-                if (last) gpcc_flag_add(&fl.colflag[8 * k + f], 1u);
-            }
+            if (chain_tile) signal_block(f);
         }
     }
+    // ---- the LAST column block by forward substitution: L_7 = (T_7 - sum_{j<7} L_j Lkk[7][j]^T) inv(D_7)^T.  Row block 7 of L_kk (out
+    // with row block 5 of the inverse) and inv(D_7) (out right behind the last 16 pivots) are all it needs: it does not wait for the
+    // last row block of the inverse -- 7 dependent block products that the diagonal step would compute when everything else of it is
+    // done (2.5 us + two barriers, and the hop from there) -- and the diagonal step does not compute that row at all any more.
+    {
+        __syncthreads();            // lbuf of column block 6 is complete (and partial buffer 1 free)
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int j = kq + 4 * c2;
+            if (j < 7) {            // (wave-uniform) A = this quarter's L_j (rows 16 rh ..), B = Lkk[7][j]: [c][k] row-major in ximg
+                const d2 b0 = b7[c2][0], b1 = b7[c2][1];
+                const d2 a0 = *(const d2 *)(lbuf + (j * 2 + rh) * 256 + lr * 16 + 4 * q), a1 = *(const d2 *)(lbuf + (j * 2 + rh) * 256 + lr * 16 + 4 * q + 2);
+                acc = P::mfma(a0[0], b0[0], acc);
+                acc = P::mfma(a0[1], b0[1], acc);
+                acc = P::mfma(a1[0], b1[0], acc);
+                acc = P::mfma(a1[1], b1[1], acc);
+            }
+        }
+        double *part = smem + 2048 + wave * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[P::crow(q, r) * 16 + lr] = acc[r];
+        if (ht && tid == 0) atomicMax(&ht[6], (unsigned long long)wall_clock64());   // column block 6 is out, the products with row block 7 of L_kk done
+        if (tid == GPCC_CHAIN_THREADS - 64) ctl[0] = gpcc_wait_ge(&fl.d7[k], 1u, fl.abortw, 0x317u) ? 1 : 0;   // inv(D_7) is out
+        __syncthreads();
+        if (!ctl[0]) return false;
+        if (ht && tid == 0) atomicMax(&ht[4], (unsigned long long)wall_clock64());
+        d2 bd0 = {0.0, 0.0}, bd1 = {0.0, 0.0};
+        if (wave < 2) {             // (in flight across the reduction below)
+            const unsigned off = (unsigned)((gpcc_bi(7, 7) + lr * 16 + 4 * q) * 8);
+            bd0 = gpcc_ld16_sc1(xres, off);
+            bd1 = gpcc_ld16_sc1(xres, off + 16u);
+        }
+        if (tid < 256) {
+            const double *pp = smem + 2048 + rh2 * 256 + rrow * 16 + 2 * sp;
+            d2 sm = *(const d2 *)pp;
+            sm += *(const d2 *)(pp + 2 * 256);
+            sm += *(const d2 *)(pp + 4 * 256);
+            sm += *(const d2 *)(pp + 6 * 256);
+            *(d2 *)(sbuf + rh2 * 256 + rrow * 16 + 2 * sp) = t7 - sm;
+        }
+        __syncthreads();
+        if (wave < 2) {             // one wave per row half: (16 x 16) times inv(D_7)^T
+            const d2 b0 = bd0, b1 = bd1;
+            const d2 a0 = *(const d2 *)(sbuf + wave * 256 + lr * 16 + 4 * q), a1 = *(const d2 *)(sbuf + wave * 256 + lr * 16 + 4 * q + 2);
+            d4 o = {0.0, 0.0, 0.0, 0.0};
+            o = P::mfma(a0[0], b0[0], o);
+            o = P::mfma(a0[1], b0[1], o);
+            o = P::mfma(a1[0], b1[0], o);
+            o = P::mfma(a1[1], b1[1], o);
+            double *ob = smem + wave * 256;   // (partial buffer 0: free since column block 6 was reduced)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ob[P::crow(q, r) * 16 + lr] = o[r];
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const d2 sm = *(const d2 *)(smem + rh2 * 256 + rrow * 16 + 2 * sp);
+            lv[7][0] = sm[0];
+            lv[7][1] = sm[1];
+            const int row = 32 * qr + 16 * rh2 + rrow;
+            gpcc_st16_sc1(tres, (unsigned)((7 * 2048 + row * 16 + ((sp ^ gpcc_sw(row)) * 2)) * 8), sm);
+            if (chain_tile) signal_block(7);
+        }
+        if (ht && tid == 0) atomicMax(&ht[5], (unsigned long long)wall_clock64());
+    }
+    // w_k (xrow = 9) is what the forward substitution below still needs
+    if (tid == GPCC_CHAIN_THREADS - 64) ctl[0] = gpcc_wait_ge(&fl.xrow[k], 9u, fl.abortw, 0x320u) ? 1 : 0;
+    __syncthreads();
+    if (!ctl[0]) return false;
     // forward substitution of logpdf's whitening: z_I[row] -= sum_c L(I,k)[row][c] w_k[c] -- AFTER the last column block is signalled
     // (the chain folds it into tile (k+1,k+1) meanwhile; z_{k+1} is wanted a block step later: gpcc_chain_diag)
-    // (xrow = 9 was seen before column block 7: w_k is there)
     if (tid < 256) {
         const double *wp = c.w + (long)slot * c.nrhs * c.Np + k * GPCC_TILE;
         double pr = 0.0;
@@ -830,8 +933,8 @@ GPCC_CHAIN_FN bool gpcc_chain_upd(const GpccCtx &c, const GpccChainFlags &fl, co
     return true;
 }
 
-// per-evaluation jobs of step k (n = nt - k - 1 tile rows below the diagonal tile): 4 n quarter solves, then n(n+1)/2 - 1 tile
-// updates (tile (k+1,k+1) belongs to the chain)
+// per-evaluation jobs of step k (n = nt - k - 1 tile rows below the diagonal tile): 4 n quarter solves + n(n+1)/2 - 1 tile updates (tile
+// (k+1,k+1) belongs to the chain) -- what the host sizes the grid by
 __host__ __device__ __forceinline__ int gpcc_chain_jobs(int n) { return n <= 0 ? 0 : 4 * n + n * (n + 1) / 2 - 1; }
 
 // grid: the chain block range (16 per 8 evaluations: blocks b and b + 8 -- one XCD, as dispatched -- are the two roles of an
@@ -842,39 +945,104 @@ __global__ __launch_bounds__(GPCC_CHAIN_THREADS, 2) void gpcc_chain_kernel(GpccC
     double *smem = (double *)smem_raw;
     int *ctl = (int *)(smem_raw + GPCC_CHAIN_LDS_BYTES - 64);
     const int b = blockIdx.x, tid0 = threadIdx.x;
-    const int ncb = 16 * ((g.cnt + 7) / 8);
+    // the dedicated range: per 8 evaluations 16 blocks for the two chain roles (b, b + 8) and, with helpers, 32 more for the four
+    // quarter solves of tile (k+1,k) -- all six workgroups of evaluation m on blocks = m (mod 8): one XCD as dispatched (a speed bonus
+    // for their hand-offs, nothing depends on it)
+    const int per8 = a.helpers ? 48 : 16;
+    const int ncb = per8 * ((g.cnt + 7) / 8);
     if (b < ncb) {
-        const int m = (b >> 4) * 8 + (b & 7), role = (b >> 3) & 1;
+        const int grp = b / per8, h = b % per8, m = grp * 8 + (h & 7);
         if (m < g.cnt) {
-            gpcc_chain_role(c, g, a, m, role, smem, ctl);
+            if (h < 16) {
+                gpcc_chain_role(c, g, a, m, (h >> 3) & 1, smem, ctl);
+            } else {
+                // chain helper: quarter q of L(k+1,k) for every step -- claimed before the diagonal step begins, so that it always runs
+                // BESIDE it (as queue jobs these were claimed behind the previous step's bulk: in the first nt/4 steps of a single
+                // evaluation only 2 us before the diagonal step ended, and the chain then waited 14 us for them)
+                const int q = (h - 16) >> 3, slot = g.slot0 + m;
+                const GpccChainFlags fl = gpcc_chain_flags(a, c.nt, m);
+                for (int k = 0; k < c.nt - 1; ++k) {
+                    int tid = tid0;
+                    asm volatile("" : "+v"(tid));
+                    if (!gpcc_chain_trsmq(c, a, fl, m, slot, k, k + 1, q, smem, ctl, tid, nullptr)) return;
+                    __syncthreads();
+                }
+            }
             return;
         }
     }
-    // ---- worker: jobs in queue order, step by step
+    // ---- worker: jobs in ONE queue order, claimed by a returning atomic add (wait-free); a claimed job waits for its inputs.  The order
+    // of the list of "step" k (n = nt - k - 1 tile rows below the diagonal tile; local tile coordinates a = I - k - 1 >= b = J - k - 1):
+    //     URGENT(k)    the 4 n quarter solves of column k (with helpers: without tile (k+1,k)'s); the updates by column k of the tiles next to the diagonal -- (k+2,k+1), (k+2,k+2),
+    //                  (k+3,k+2), ...: what the chain waits for one or two steps later; the rest of local column 0 (the next step's solves);
+    //     FAR(k - 1)   the updates by column k - 1 of the other tiles from local column 2 on (the bulk: ~n^2/2 jobs), ONE STEP LATE;
+    //     NEAR1(k)     the updates by column k of the rest of local column 1.
+    // Every job's inputs are produced by jobs EARLIER in this order or by the chain (the solves of step k need local column 0 of step
+    // k-1; local column 0 of step k was local column 1 of step k-1 (NEAR1); FAR(k-1) needs step k-1's solves and FAR(k-2) / NEAR1(k-2);
+    // NEAR1(k) was local column 2 of step k-1: FAR(k-1), just in front), so the oldest unfinished job can always run: no deadlock
+    // whatever is resident.  Why the bulk is one step late: in plain step order the urgent jobs of step k were claimed only after every
+    // bulk job of step k - 1 had been -- in the first nt/4 steps that is two rounds of 23 us jobs on 254 CUs, and the chain of a single
+    // evaluation waited 16 us instead of 5 between its diagonal steps (profiles/r05/chain_trace_first_version.log).
     int ks = 0;
     for (;;) {
         int tid = tid0;
         asm volatile("" : "+v"(tid));   // (per-job opaque copy, as in gpcc_chain_role)
         if (tid == 0) {
             int j = -1;
-            while (ks < c.nt - 1) {
-                const int nj = g.cnt * gpcc_chain_jobs(c.nt - ks - 1);
-                const int t = (int)gpcc_flag_add(&a.words[16 + ks], 1u);
+            while (ks < c.nt) {
+                const int n = c.nt - ks - 1, np = n + 1;   // np: rows below the diagonal tile of step ks - 1
+                const int nsol = n >= 1 ? 4 * (n - (a.helpers ? 1 : 0)) : 0;   // (with helpers the solves of tile (k+1,k) are not queue jobs)
+                const int urgent = n >= 1 ? nsol + 2 * (n - 1) + (n >= 3 ? n - 2 : 0) : 0;
+                const int far = (ks >= 1 && np >= 5) ? (np - 4) * (np - 3) / 2 : 0;
+                const int near = n >= 4 ? n - 3 : 0;
+                const int nj = g.cnt * (urgent + far + near);
+                const int t = (nj > 0) ? (int)gpcc_flag_add(&a.words[16 + ks], 1u) : 0;
                 if (t < nj) {
                     j = t;
                     break;
                 }
                 ++ks;
             }
-            ctl[1] = j;
-            ctl[2] = ks;
+            int kind = -1, jk = 0, jI = 0, jJ = 0;
+            if (j >= 0) {
+                const int n = c.nt - ks - 1, np = n + 1;
+                const int nsol = n >= 1 ? 4 * (n - (a.helpers ? 1 : 0)) : 0;
+                const int band = n >= 1 ? nsol + 2 * (n - 1) : 0;
+                const int urgent = band + (n >= 3 ? n - 2 : 0);
+                const int far = (ks >= 1 && np >= 5) ? (np - 4) * (np - 3) / 2 : 0;
+                int jj = j / g.cnt, ra, rb;
+                if (jj < nsol) {                  // quarter solve (I, ks, q)
+                    kind = 1; jk = ks; jI = ks + 1 + (a.helpers ? 1 : 0) + jj / 4; jJ = jj % 4;
+                } else if (jj < band) {           // next to the diagonal: (k+2,k+1), (k+2,k+2), (k+3,k+2), (k+3,k+3), ...
+                    const int bnd = jj - nsol;
+                    ra = 1 + bnd / 2;
+                    rb = (bnd & 1) ? ra : ra - 1;
+                    kind = 2; jk = ks; jI = ks + 1 + ra; jJ = ks + 1 + rb;
+                } else if (jj < urgent) {         // the rest of local column 0 -- the column the NEXT step solves: (k+3.., k+1)
+                    ra = 2 + (jj - band);
+                    kind = 2; jk = ks; jI = ks + 1 + ra; jJ = ks + 1;
+                } else if (jj < urgent + far) {   // the bulk of step ks - 1: local columns rb = 2 .. np - 3, rows ra = rb + 2 .. np - 1
+                    int u = jj - urgent;
+                    rb = 2;
+                    while (u >= np - 2 - rb) {
+                        u -= np - 2 - rb;
+                        ++rb;
+                    }
+                    ra = rb + 2 + u;
+                    kind = 2; jk = ks - 1; jI = ks + ra; jJ = ks + rb;
+                } else {                          // the rest of local column 1 of this step: (k+4.., k+2)
+                    ra = 3 + (jj - urgent - far);
+                    kind = 2; jk = ks; jI = ks + 1 + ra; jJ = ks + 2;
+                }
+            }
+            ctl[1] = kind; ctl[2] = jk; ctl[5] = (j >= 0) ? j % g.cnt : 0; ctl[6] = jI; ctl[7] = jJ; ctl[3] = ks;
         }
         __syncthreads();
-        const int j = ctl[1];
-        ks = ctl[2];
+        const int kind = ctl[1], k = ctl[2], m = ctl[5], jI = ctl[6], jJ = ctl[7];
+        ks = ctl[3];
         __syncthreads();   // (ctl is rewritten by the job's own waits)
-        if (j < 0) return;
-        const int m = j % g.cnt, jj = j / g.cnt, k = ks, n = c.nt - k - 1, slot = g.slot0 + m;
+        if (kind < 0) return;
+        const int slot = g.slot0 + m;
         const GpccChainFlags fl = gpcc_chain_flags(a, c.nt, m);
         unsigned long long *wt = nullptr;
         if (a.wtrace) {
@@ -882,29 +1050,13 @@ __global__ __launch_bounds__(GPCC_CHAIN_THREADS, 2) void gpcc_chain_kernel(GpccC
             __syncthreads();
             if (ctl[4] < a.wtrace_cap) wt = a.wtrace + 4L * ctl[4];
             if (wt && tid == 0) {
-                wt[0] = ((unsigned long long)(jj < 4 * n ? 1 : 2) << 56) | ((unsigned long long)k << 32) | (unsigned)jj;
+                wt[0] = ((unsigned long long)kind << 56) | ((unsigned long long)k << 32) | (unsigned)(jI * 1024 + jJ);
                 wt[1] = wall_clock64();
             }
         }
         bool ok;
-        if (jj < 4 * n) {
-            ok = gpcc_chain_trsmq(c, a, fl, m, slot, k, k + 1 + jj / 4, jj % 4, smem, ctl, tid, wt);
-        } else {
-            const int u = jj - 4 * n;
-            int ra, rb;   // tile (k + 1 + ra, k + 1 + rb), rb <= ra, (0,0) excluded: column k + 1 first (the next step's solves wait for it)
-            if (u < n - 1) {
-                ra = u + 1;
-                rb = 0;
-            } else {
-                const int v = u - (n - 1);   // pairs 1 <= rb <= ra <= n - 1, row-major
-                int t = (int)((sqrtf(8.0f * v + 1.0f) - 1.0f) * 0.5f);
-                while (t * (t + 1) / 2 > v) --t;
-                while ((t + 1) * (t + 2) / 2 <= v) ++t;
-                ra = 1 + t;
-                rb = 1 + (v - t * (t + 1) / 2);
-            }
-            ok = gpcc_chain_upd(c, fl, slot, k, k + 1 + ra, k + 1 + rb, smem, ctl, tid, wt);
-        }
+        if (kind == 1) ok = gpcc_chain_trsmq(c, a, fl, m, slot, k, jI, jJ, smem, ctl, tid, wt);
+        else ok = gpcc_chain_upd(c, fl, slot, k, jI, jJ, smem, ctl, tid, wt);
         if (!ok) return;
         if (wt && tid == 0) wt[3] = wall_clock64();
         __syncthreads();

@@ -123,6 +123,8 @@ struct gpcc_handle_s {
     int fused_small_max = 12;  // groups of at most this many evaluations run gpcc_small_step (update + next diagonal step in one launch)
     int chain_max = 12;        // option "chain_max": ... or, fp64 handles, as ONE persistent launch (gpcc_chain.hip.h); 0 = never
     std::atomic<long> chain_count{0};   // evaluations that took the persistent launch so far ("chain_count")
+    int chain_helpers_max = 6; // option "chain_helpers_max": groups of at most this many evaluations give each evaluation four more dedicated workgroups
+                               // (the quarter solves of the tile below the diagonal run beside every diagonal step instead of being queue jobs)
     int chain_trace = 0;       // option "chain_trace": the chain workgroups stamp their phases (gpcc_chain_trace; tools/chain_trace.py)
     unsigned *d_chain_words = nullptr;             // per workspace stream: the launch's flag words (zeroed before every launch)
     double *d_ximg = nullptr, *d_stepval = nullptr;   // ... the published inverses of the diagonal blocks, the steps' scalars
@@ -493,6 +495,9 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
     } else if (!strcmp(key, "chain_max")) {
         if (v < 0 || v > GPCC_CHAIN_MAX_EVALS) return fail(h, GPCC_ERR_ARGUMENT, "chain_max must be in [0,%d]", GPCC_CHAIN_MAX_EVALS);
         h->chain_max = (int)v;
+    } else if (!strcmp(key, "chain_helpers_max")) {
+        if (v < 0 || v > GPCC_CHAIN_MAX_EVALS) return fail(h, GPCC_ERR_ARGUMENT, "chain_helpers_max must be in [0,%d]", GPCC_CHAIN_MAX_EVALS);
+        h->chain_helpers_max = (int)v;
     } else if (!strcmp(key, "chain_trace")) {
         h->chain_trace = v != 0;
         if (h->chain_trace && !h->d_chain_trace) h->chain_streams = 0;   // (the buffers are rebuilt with a trace area on the next launch)
@@ -566,6 +571,7 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "chain_max")) return h->chain_max;
     if (!strcmp(key, "chain_count")) return h->chain_count;
     if (!strcmp(key, "chain_trace")) return h->chain_trace;
+    if (!strcmp(key, "chain_helpers_max")) return h->chain_helpers_max;
     if (!strcmp(key, "shared_prefix")) return h->shared_prefix;
     if (!strcmp(key, "share_tiles")) return h->share_tiles;
     if (!strcmp(key, "N")) return h->N;
@@ -658,8 +664,8 @@ static int ensure_chain(gpcc_handle_t h)
     hipFree(h->d_chain_words); hipFree(h->d_ximg); hipFree(h->d_stepval); hipFree(h->d_chain_trace);
     h->d_chain_words = nullptr; h->d_ximg = h->d_stepval = nullptr; h->d_chain_trace = nullptr; h->chain_streams = 0;
     const long ntiles = (long)h->nt * (h->nt + 1) / 2;
-    h->chain_qbase = 16 + (h->nt + 15) / 16 * 16;
-    h->chain_ev_words = (int)((9L * h->nt + 2 * ntiles + 3) / 4 * 4);
+    h->chain_qbase = 16 + 2 * ((h->nt + 15) / 16 * 16);   // abort word + trace counter, then the urgent and the bulk queue's counter per step
+    h->chain_ev_words = (int)((10L * h->nt + 2 * ntiles + 3) / 4 * 4);   // xrow, d7, colflag[8] per step; lcnt, ver per tile
     h->chain_region_words = ((long)h->chain_qbase + (long)GPCC_CHAIN_MAX_EVALS * h->chain_ev_words + 63) / 64 * 64;
     const long S = h->ws_streams, E = GPCC_CHAIN_MAX_EVALS;
     HIPCHK(h, hipMalloc(&h->d_chain_words, sizeof(unsigned) * h->chain_region_words * S));
@@ -700,6 +706,7 @@ static GpccChainArgs chain_args(gpcc_handle_t h, const GpccCtx &c, const GpccGro
     a.wtrace_cap = GPCC_CHAIN_WTRACE_CAP;
     a.ev_words = h->chain_ev_words;
     a.qbase = h->chain_qbase;
+    a.helpers = (g.cnt <= h->chain_helpers_max) ? 1 : 0;
     return a;
 }
 
@@ -899,12 +906,13 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
         // (gpcc_chain.hip.h)
         ProfScope pr(h, GPCC_PROF_SMALL_STEP, s);
         const GpccChainArgs a = chain_args(h, c, g);   // (its flag words were zeroed by the assembly launch in front: GpccCtx::chain_words)
-        const int ncb = 16 * ((g.cnt + 7) / 8);
+        const int dedicated = (a.helpers ? 6 : 2) * g.cnt;                 // chain roles (+ the four solve helpers) per evaluation
+        const int ncb = (a.helpers ? 48 : 16) * ((g.cnt + 7) / 8);         // their block range
         long workers = (long)g.cnt * gpcc_chain_jobs(c.nt - 1);   // the widest step; more workgroups than that would only spin
-        const long room = (long)h->n_cus - 2 * g.cnt;
+        const long room = (long)h->n_cus - dedicated;
         if (workers > room) workers = room;
         if (workers < 1) workers = 1;
-        const long grid = (2L * g.cnt + workers > ncb) ? 2L * g.cnt + workers : ncb;   // (blocks of the chain range without a role work too)
+        const long grid = (dedicated + workers > ncb) ? dedicated + workers : ncb;   // (blocks of the dedicated range without a role work too)
         gpcc_chain_kernel<<<(unsigned)grid, GPCC_CHAIN_THREADS, GPCC_CHAIN_LDS_BYTES, s>>>(c, g, a);
         h->chain_count += g.cnt;
         return;
@@ -2436,13 +2444,17 @@ extern "C" int gpcc_chain_jobs_trace(gpcc_handle_t h, double *out, long capacity
     if (n > 0) HIPCHK(h, hipMemcpy(st.data(), src, sizeof(unsigned long long) * 4 * n, hipMemcpyDeviceToHost));
     int khz = 100000;
     (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device);
-    unsigned long long t0 = ~0ull;
-    for (long i = 0; i < n; ++i) if (st[4 * i + 1] && st[4 * i + 1] < t0) t0 = st[4 * i + 1];
+    unsigned long long t0 = 0;   // the same origin as gpcc_chain_trace(evaluation 0): the first stamp of its chain
+    HIPCHK(h, hipMemcpy(&t0, h->d_chain_trace, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (!t0) {
+        t0 = ~0ull;
+        for (long i = 0; i < n; ++i) if (st[4 * i + 1] && st[4 * i + 1] < t0) t0 = st[4 * i + 1];
+    }
     for (long i = 0; i < n; ++i) {
         out[6 * i] = (double)(st[4 * i] >> 56);
         out[6 * i + 1] = (double)((st[4 * i] >> 32) & 0xffffff);
         out[6 * i + 2] = (double)(st[4 * i] & 0xffffffffu);
-        for (int e = 1; e < 4; ++e) out[6 * i + 2 + e] = st[4 * i + e] ? (double)(st[4 * i + e] - t0) * 1e3 / khz : -1.0;
+        for (int e = 1; e < 4; ++e) out[6 * i + 2 + e] = st[4 * i + e] ? ((double)st[4 * i + e] - (double)t0) * 1e3 / khz : -1.0;
     }
     *rows_out = n;
     return 0;

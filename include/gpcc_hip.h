@@ -104,6 +104,8 @@ int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms
  *                                     (gpcc_chain: two chain workgroups per evaluation carry diagonal step -> column solve -> next
  *                                     diagonal tile without leaving their CUs, all other CUs pull trailing-update jobs; fp64 handles);
  *                                     0 = the two-launches-per-step path below
+ *   chain_helpers_max        6        ... with four more dedicated workgroups per evaluation (the solves of the tile below the diagonal run
+ *                                     beside every diagonal step) for groups of at most this many evaluations
  *   fused_small_max          12       ... otherwise such groups run gpcc_panel_trsm_rows + gpcc_small_step (2 launches per step)
  *   right_looking_max        12       groups of at most this many evaluations factorise right-looking
  *   fused_solve              1        larger groups: panel solve inside the update kernel (gpcc_syrk_diag + gpcc_update_solve);

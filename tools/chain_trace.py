@@ -52,6 +52,12 @@ with gpcc_amd.Objective(t, y, s, "matern32", slots_per_stream=16) as obj:
             print("   jb %d: %s | %5.2f | %5.2f | %5.2f" % (jb, w0, b[jb, 2] - b[jb, 1], (b[jb, 3] if jb < 8 else nxt) - b[jb, 2], nxt - b[jb, 0]))
         print("sum of hand-offs %.1f us (mean %.2f), sum of diagonal steps %.1f us (mean %.2f)" % (
             sum(hand[1:]), np.mean(hand[1:]) if nt > 1 else 0.0, sum(diag), np.mean(diag)))
+        if nt > 2:
+            print("the hand-off in detail (us after the first stamp of step k's last 16 pivots [block step 7 begins]): inv(D_7) flagged | the last of the four quarters of tile (k+1,k): column block 6 out, "
+                  "inv(D_7) seen, column block 7 out | chain of step k+1: block 7 seen, image complete | step k published")
+            for k in range(nt // 2 - 2, nt // 2 + 3):
+                o = tr[k, 8 + 8 * 7]
+                print("   k=%2d: %6.2f | %6.2f %6.2f %6.2f | %6.2f %6.2f | %6.2f" % (k, tr[k, 3] - o, tr[k, 6] - o, tr[k, 4] - o, tr[k, 5] - o, tr[k + 1, 7] - o, tr[k + 1, 1] - o, tr[k, 2] - o))
     jt = obj.chain_jobs_trace()
     if len(jt):
         print("== workers: %d jobs stamped (whole group)" % len(jt))
@@ -64,3 +70,13 @@ with gpcc_amd.Objective(t, y, s, "matern32", slots_per_stream=16) as obj:
         span = jt[:, 5].max() - jt[:, 3].min()
         busy = (jt[:, 5] - jt[:, 4]).sum()
         print("   span %.1f us; sum of running time %.1f us = %.1f workgroups busy on average" % (span, busy, busy / span))
+        if M == 1:
+            tr = obj.chain_trace(0)
+            print("== what the chain of step k waited for (us, same clock): step k-1 published | last quarter solve of tile (k,k-1) claimed / inputs there / done |")
+            print("   update of (k,k-1) by column k-2 done | update of (k,k) by column k-2 done | image of tile (k,k) complete")
+            for k in range(2, min(nt, 14)):
+                sol = jt[(jt[:, 0] == 1) & (jt[:, 1] == k - 1) & (jt[:, 2] // 1024 == k)]
+                u1 = jt[(jt[:, 0] == 2) & (jt[:, 1] == k - 2) & (jt[:, 2] == k * 1024 + k - 1)]
+                u2 = jt[(jt[:, 0] == 2) & (jt[:, 1] == k - 2) & (jt[:, 2] == k * 1024 + k)]
+                f = lambda r, c: ("%8.1f" % r[:, c].max()) if len(r) else "       -"
+                print("   k=%2d: %8.1f | %s / %s / %s | %s | %s | %8.1f" % (k, tr[k - 1, 2], f(sol, 3), f(sol, 4), f(sol, 5), f(u1, 5), f(u2, 5), tr[k, 1]))
