@@ -43,6 +43,7 @@
 #define GPCC_CHAIN_SPIN_LIMIT (1u << 22)
 #define GPCC_CHAIN_MAXRHS 4
 #define GPCC_CHAIN_TLD 18
+#define GPCC_XIMG_STRIDE (GPCC_XIMG_ELEMS + 16 * GPCC_TILE)   /* doubles per (evaluation, step): the published blocks of L_kk, then S7 (gpcc_chain_trsmq) */
 #define GPCC_CHAIN_TMP_OFF (GPCC_XIMG_ELEMS + GPCC_CHAIN_MAXRHS * GPCC_TILE + GPCC_TILE + 2)   /* doubles: gpcc_chain_diag's stmp */
 #define GPCC_XIMG_ELEMS (36 * 256)         /* the lower 36 blocks of inv(L_kk), 16 x 16 row-major each */
 #define GPCC_INFO_TIMEOUT (-9)
@@ -58,8 +59,9 @@ typedef unsigned gpcc_u4 __attribute__((ext_vector_type(4)));
 struct GpccChainArgs {
     unsigned *words;             // zeroed before every launch: [0] abort word; [16 + k] job counter of step k (k = 0 .. nt - 1); from qbase on, per
                                  // evaluation (ev_words each):
-                                 //   xrow[nt] | d7[nt] | colflag[nt][8] | lcnt[ntiles] | ver[ntiles]
-    double *ximg;                // evaluations x nt x GPCC_XIMG_ELEMS: inv(L_kk) as published (block (f, ch) at gpcc_bi(f, ch), [row][col] row-major)
+                                 //   xrow[nt] | l7[nt] | colflag[nt][8] | lcnt[ntiles] | ver[ntiles]
+    double *ximg;                // evaluations x nt x GPCC_XIMG_STRIDE: row blocks of L_kk and the inv(D_f) as published (block (f, j) at gpcc_bi(f, j), row-major),
+                                 // then S7: the last column block of L(k+1,k) before its product with inv(D_7)^T, in the tile's chunk layout
     double *stepval;             // evaluations x nt x GPCC_CHAIN_STEPVALS: per diagonal step [sum log L_ii of the block, first bad pivot, W'W]
     unsigned long long *trace;   // optional (NULL): evaluations x nt x GPCC_CHAIN_TRACE_WORDS wall-clock stamps of the chain (tools/chain_trace.py)
     unsigned long long *wtrace;  // optional (NULL): wtrace_cap x 4 stamps of the workers' jobs: [kind | step | tile, fetched, dependencies met, done]; words[1] counts
@@ -68,6 +70,7 @@ struct GpccChainArgs {
     int qbase;                   // first per-evaluation word
     int helpers;                 // 1: four more dedicated workgroups per evaluation run the quarter solves of the tile below the diagonal
                                  //    (few evaluations: latency); 0: those solves are queue jobs like the others (more workers)
+    int quarters;                // 1: the updates the next step needs at once are queue jobs of a quarter tile (gpcc_chain_updq); 0: whole tiles
 };
 
 // ---- agent-scope accesses (all hand-off traffic): relaxed atomics lower to global_load / global_store ... sc1
@@ -103,6 +106,11 @@ __device__ __forceinline__ void gpcc_dma_piece2_sc1(const void *gbase, unsigned 
                  : "s"(lds_addr), "v"(voff), "s"(gbase)
                  : "memory", "m0");
 }
+// one 1 KiB piece
+__device__ __forceinline__ void gpcc_dma_piece1_sc1(const void *gbase, unsigned voff, unsigned lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1" : : "s"(lds_addr), "v"(voff), "s"(gbase) : "memory", "m0");
+}
 __device__ __forceinline__ void gpcc_dma_chunk_sc1(const double *gA, const double *gB, unsigned stage_addr, int wave, int lane)
 {
     const int uw = __builtin_amdgcn_readfirstlane(wave);
@@ -127,7 +135,7 @@ __device__ __forceinline__ bool gpcc_wait_ge(const unsigned *p, unsigned want, u
 __device__ __forceinline__ int gpcc_tile_idx(int I, int J) { return I * (I + 1) / 2 + J; }
 // the flag words of evaluation m
 struct GpccChainFlags {
-    unsigned *abortw, *xrow, *d7, *colflag, *lcnt, *ver;
+    unsigned *abortw, *xrow, *l7, *colflag, *lcnt, *ver;
 };
 __device__ __forceinline__ GpccChainFlags gpcc_chain_flags(const GpccChainArgs &a, int nt, int m)
 {
@@ -136,7 +144,7 @@ __device__ __forceinline__ GpccChainFlags gpcc_chain_flags(const GpccChainArgs &
     const int ntiles = nt * (nt + 1) / 2;
     f.abortw = a.words;
     f.xrow = ev;
-    f.d7 = ev + nt;
+    f.l7 = ev + nt;
     f.colflag = ev + 2 * nt;
     f.lcnt = ev + 10 * nt;
     f.ver = ev + 10 * nt + ntiles;
@@ -177,6 +185,26 @@ __device__ __forceinline__ void gpcc_chain_publish_block(const double *sB, __amd
     gpcc_st16_sc1(xr, off + 16u, hi);
 }
 
+// z_r2 -= L[r2][i] w_i (one wave; the right-hand sides along the lanes' n index, padded with zeros)
+__device__ __forceinline__ void gpcc_chain_zupdate(const double *sB, double *sz, int r2, int i, int nrhs, int lrv, int qv)
+{
+    typedef GpccPrec<double> PD;
+    const int zrow = (lrv < nrhs) ? lrv : 0;
+    d4 S;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S[r] = sz[zrow * GPCC_TILE + r2 * 16 + qv + 4 * r];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+        const double av = -sB[gpcc_bi(r2, i) + gpcc_be(lrv, qv + 4 * s2)];      // L[r2][i]
+        const double wv = sz[zrow * GPCC_TILE + i * 16 + qv + 4 * s2];
+        S = PD::mfma(av, (lrv < nrhs) ? wv : 0.0, S);
+    }
+    if (lrv < nrhs) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sz[lrv * GPCC_TILE + r2 * 16 + qv + 4 * r] = S[r];
+    }
+}
+
 // PRE: the image (36 blocks at smem) holds the updated lower triangle of tile (k,k), behind a barrier.  Returns false if abandoned.
 GPCC_CHAIN_FN void gpcc_chain_diag(const GpccCtx &c, const GpccGroup &g, const GpccChainArgs &a, const GpccChainFlags &fl, const int k,
                                    const int m, double *smem, const int tid)
@@ -195,7 +223,7 @@ GPCC_CHAIN_FN void gpcc_chain_diag(const GpccCtx &c, const GpccGroup &g, const G
     const int wk = (wave == 0 || wave == 4) ? -1 : (wave < 4 ? wave - 1 : wave - 2);
     const int slot = g.slot0 + m, nrhs = c.nrhs;
     const bool last = (k == c.nt - 1);
-    double *xk = a.ximg + ((long)m * c.nt + k) * GPCC_XIMG_ELEMS;
+    double *xk = a.ximg + ((long)m * c.nt + k) * GPCC_XIMG_STRIDE;
     const __amdgpu_buffer_rsrc_t xr = gpcc_rsrc(xk, GPCC_XIMG_ELEMS * 8);
 
     if (tid == 0) *sbad = 0;
@@ -206,8 +234,6 @@ GPCC_CHAIN_FN void gpcc_chain_diag(const GpccCtx &c, const GpccGroup &g, const G
         const int r0 = jb * 16;
         int lrv = lr, qv = q;   // opaque per-phase copies: keeps the compiler from hoisting every lane-dependent address of all nine rounds out of the loop
         GPCC_OPAQUE_LANE(lrv, qv);
-        d4 xo[2];            // rows of inv(L) built in this round: written after the barrier (in place of L's row)
-        int xj[2] = {-1, -1};
         if (wave == 6 && jb == 0) {
             // z_k: the right-hand side of this step's forward substitution.  Its last update -- z_k -= L(k,k-1) w_{k-1} -- is the END of the
             // four quarter solves of tile (k,k-1) (lcnt = 4), a hand-off later than the last column block this workgroup has just folded
@@ -218,17 +244,15 @@ GPCC_CHAIN_FN void gpcc_chain_diag(const GpccCtx &c, const GpccGroup &g, const G
             for (int e = lane; e < nrhs * GPCC_TILE; e += 64)
                 sz[e] = gpcc_ld_sc1(c.z + ((long)slot * nrhs + e / GPCC_TILE) * c.Np + k * GPCC_TILE + (e % GPCC_TILE));
         }
-        if (wave == 6 && jb >= 2) {   // row block jb - 2 of inv(L) is final: out it goes (nothing of it is written any more)
-            // (wave 6 -- a worker with time to spare: wave 4, which has nothing else to do, shares wave 0's SIMD, and whatever it issues
-            //  there is taken from the pivot chain's issue slots)
-            // The LAST row block of inv(L) is never built: a solve finishes its last column block by forward substitution from row
-            // block 7 of L itself (final since the panel of column block 6: out now, with row block 5 of the inverse) and inv(D_7) (out
-            // right behind the last 16 pivots, below: d7)
-            if (jb == 7)
-                for (int j = 0; j <= 6; ++j) gpcc_chain_publish_block(sB, xr, 7, j, lane);
-            for (int j = 0; j <= jb - 2; ++j) gpcc_chain_publish_block(sB, xr, jb - 2, j, lane);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) gpcc_flag_st(&fl.xrow[k], (unsigned)(jb - 1));
+        if (wave == 7 && jb >= 1 && jb < 8) {
+            // row block jb of L_kk (columns 0 .. jb-1) is final since the panel of column block jb - 1: out it goes, beside the 16 pivots of
+            // D_jb; the flag follows with inv(D_jb) behind the barrier below.  (Wave 7: never has a panel task, and does not share wave
+            // 0's SIMD -- whatever wave 4 issued would be taken from the pivot chain's issue slots.)
+            for (int j = 0; j < jb; ++j) gpcc_chain_publish_block(sB, xr, jb, j, lane);
+            if (jb == 7) {   // the last row block gets a flag of its own: S7 (gpcc_chain_trsmq) is built from it while the last 16 pivots run
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) gpcc_flag_st(&fl.l7[k], 1u);
+            }
         }
         if (wave == 0) {
             if (jb > 0 && jb < 8) {   // C(jb-1) for the block the factorisation below needs: D_jb -= P_jb P_jb^T
@@ -326,97 +350,41 @@ GPCC_CHAIN_FN void gpcc_chain_diag(const GpccCtx &c, const GpccGroup &g, const G
             }
         }
         GPCC_OPAQUE_LANE(lrv, qv);
-        if (jb > 0) {
-            // ---- (X) row i = jb-1 of inv(L) and (W) rows i of W_k, one task per worker (the last row: all eight waves)
+        if (jb > 0 && wave == 1) {
+            // ---- (W) w_i = inv(D_i) z_i for i = jb - 1: z_i has received every earlier w (phase 2 of the iterations before, below)
             const int i = jb - 1;
-            bool dow = false;
-            int j0 = -1, j1 = -1;
-            if (jb == 8) {
-                dow = wave == 0;     // (W only: the last row block of the inverse is not needed, see above)
-            } else if (wk >= 0) {
-                dow = wk == 0;
-                j0 = wk - 1;
-                j1 = (wk == NWK - 1) ? NWK - 1 : -1;
+            const int zrow = (lrv < nrhs) ? lrv : 0;
+            d4 Y = {0.0, 0.0, 0.0, 0.0}, Y1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double dv = sB[gpcc_bi(i, i) + gpcc_be(qv + 4 * r, lrv)];           // inv(D_i)[lrv][qv + 4 r]
+                const double zv = sz[zrow * GPCC_TILE + i * 16 + qv + 4 * r];
+                const double bv = (lrv < nrhs) ? zv : 0.0;
+                if (r & 1) Y1 = PD::mfma(dv, bv, Y1);
+                else Y = PD::mfma(dv, bv, Y);
             }
-            if (dow) {
-                const int zrow = (lrv < nrhs) ? lrv : 0;
-                d4 S, S1 = {0.0, 0.0, 0.0, 0.0};
+            if (lrv < nrhs) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double zv = sz[zrow * GPCC_TILE + i * 16 + qv + 4 * r];
-                    S[r] = (lrv < nrhs) ? -zv : 0.0;
-                }
-                for (int mm = 0; mm < i; ++mm) {
-#pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2) {
-                        const double av = sB[gpcc_bi(i, mm) + gpcc_be(lrv, qv + 4 * s2)];      // L[i][mm]
-                        const double wv = sz[zrow * GPCC_TILE + mm * 16 + qv + 4 * s2];
-                        const double bv = (lrv < nrhs) ? wv : 0.0;
-                        if (s2 & 1) S1 = PD::mfma(av, bv, S1);
-                        else S = PD::mfma(av, bv, S);
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) S[r] += S1[r];
-                d4 Y = {0.0, 0.0, 0.0, 0.0}, Y1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double dv = -sB[gpcc_bi(i, i) + gpcc_be(qv + 4 * r, lrv)];           // inv(D_i)[lrv][qv + 4 r]
-                    if (r & 1) Y1 = PD::mfma(dv, S[r], Y1);
-                    else Y = PD::mfma(dv, S[r], Y);
-                }
-                if (lrv < nrhs) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sz[lrv * GPCC_TILE + i * 16 + qv + 4 * r] = Y[r] + Y1[r];
-                }
-            }
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int j = n ? j1 : j0;
-                if (j < 0 || j >= i) continue;
-                d4 S = {0.0, 0.0, 0.0, 0.0}, S1 = {0.0, 0.0, 0.0, 0.0};
-                for (int mm = j; mm < i; ++mm) {
-#pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2) {
-                        const double av = sB[gpcc_bi(i, mm) + gpcc_be(lrv, qv + 4 * s2)];                     // L[i][mm]
-                        const double bv = (mm == j) ? sB[gpcc_bi(j, j) + gpcc_be(lrv, qv + 4 * s2)]           // X[j][j][k][c]
-                                                    : sB[gpcc_bi(mm, j) + gpcc_be(qv + 4 * s2, lrv)];         // X[mm][j][k][c]
-                        if (s2 & 1) S1 = PD::mfma(av, bv, S1);
-                        else S = PD::mfma(av, bv, S);
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) S[r] += S1[r];
-                d4 Y = {0.0, 0.0, 0.0, 0.0}, Y1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double dv = -sB[gpcc_bi(i, i) + gpcc_be(qv + 4 * r, lrv)];
-                    if (r & 1) Y1 = PD::mfma(dv, S[r], Y1);
-                    else Y = PD::mfma(dv, S[r], Y);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xo[n][r] = Y[r] + Y1[r];
-                xj[n] = j;
+                for (int r = 0; r < 4; ++r) sz[lrv * GPCC_TILE + i * 16 + qv + 4 * r] = Y[r] + Y1[r];
             }
         }
         if (trd && tid == 0) trd[8 * jb + 1] = wall_clock64();
         __syncthreads();   // every reader of L's row jb-1 is done
         if (trd && tid == 0) trd[8 * jb + 2] = wall_clock64();
-        if (jb == 7 && wave == 6) {   // inv(D_7) is in the image: out at once, with a flag of its own -- the solves' last column block waits for it
-            gpcc_chain_publish_block(sB, xr, 7, 7, lane);
+        if (jb < 8 && wave == 7) {   // inv(D_jb) is in the image: out at once; every store of this wave -- row block jb of L too -- has drained before the flag
+            gpcc_chain_publish_block(sB, xr, jb, jb, lane);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) gpcc_flag_st(&fl.d7[k], 1u);
-            if (trd && lane == 0) trd[-5] = wall_clock64();   // (header word 3)
+            if (lane == 0) gpcc_flag_st(&fl.xrow[k], (unsigned)(jb + 1));
+            if (trd && jb == 7 && lane == 0) trd[-5] = wall_clock64();   // (header word 3)
         }
         GPCC_OPAQUE_LANE(lrv, qv);
-        if (jb > 0) {
-            const int i = jb - 1;
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-                if (xj[n] >= 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sB[gpcc_bi(i, xj[n]) + gpcc_be(qv + 4 * r, lrv)] = xo[n][r];   // X[i][j], untransposed
-                }
+        if (jb > 0 && jb < 8) {
+            // ---- (Z) z_r -= L[r][jb-1] w_{jb-1} for the rows below, one task per wave from wave 6 down (right-looking: the last w needs
+            // ONE block product when its turn comes, not a chain of eight).  (Measured: only row jb here and the others beside the next
+            // 16 pivots on one wave -- on wave 4, idle but on wave 0's SIMD, the pivots slow down by 0.2-0.9 us per block; on wave 5 the
+            // six tasks in a row outlast the pivots.)
+            const int r2 = jb + (6 - wave);
+            if (wave <= 6 && r2 < 8) gpcc_chain_zupdate(sB, sz, r2, jb - 1, nrhs, lrv, qv);
         }
         if (jb == 8) break;
         GPCC_OPAQUE_LANE(lrv, qv);
@@ -492,8 +460,8 @@ GPCC_CHAIN_FN void gpcc_chain_diag(const GpccCtx &c, const GpccGroup &g, const G
 // into one of two LDS stages.  Returns false if abandoned.
 // ------------------------------------------------------------------------------------------
 template <int RA, int CA, int NA, int RB, int CB, int NB>
-GPCC_CHAIN_FN bool gpcc_chain_syrk_wave(const double *Tt, const double *Lt, const unsigned *colflag, unsigned *abortw, double *smem, int *ctl,
-                                                     int tid, int lane, unsigned long long *tr)
+GPCC_CHAIN_FN bool gpcc_chain_syrk_wave(const double *Tt, const double *Lt, const double *xprev, const unsigned *colflag, const unsigned *xrowp,
+                                        unsigned *abortw, double *smem, int *ctl, int tid, int lane, unsigned long long *tr)
 {
     typedef GpccPrec<double> P;
     const int lr = lane & 15, q = lane >> 4, sw = gpcc_sw(lr);
@@ -508,18 +476,59 @@ GPCC_CHAIN_FN bool gpcc_chain_syrk_wave(const double *Tt, const double *Lt, cons
     const unsigned smem_addr = gpcc_lds_addr(smem);
     const double *p0 = smem + lr * 16 + (((2 * q) ^ sw) * 2);
     const double *p1 = smem + lr * 16 + (((2 * q + 1) ^ sw) * 2);
+    d2 a70 = {0.0, 0.0}, a71 = {0.0, 0.0};
+    int issued = -1;       // last column block whose copy this wave has issued
+    unsigned peek = (lane == 0) ? gpcc_flag_ld(&colflag[1]) : 0u;    // colflag of the NEXT block as read a block earlier (lane 0): a workgroup that is behind -- its tile's other
+                           // update came late, all of L(k,k-1) is there already -- copies block ch + 1 beside the products of block ch
     for (int ch = 0; ch < 8; ++ch) {
         // every wave polls for itself (one lane) and copies ITS 2 KiB of the column block into stage ch & 1 by LDS-DMA the moment the
         // fourth quarter has signalled it: one barrier per block (the stage written now was last read two blocks ago, and every wave
         // has passed the barrier in between)
         int okw = 1;
-        if (lane == 0) okw = gpcc_wait_ge(&colflag[ch], 4u, abortw, 0x100u + ch) ? 1 : 0;
-        okw = __builtin_amdgcn_readfirstlane(okw);
+        if (ch == 7) {   // inv(D_7) of the step before: flagged well before S7 can be -- requested first, in flight while S7 is waited for and copied
+            if (lane == 0) okw = gpcc_wait_ge(xrowp, 8u, abortw, 0x108u) ? 1 : 0;
+            okw = __builtin_amdgcn_readfirstlane(okw);
+            const double *xd = xprev + gpcc_bi(7, 7) + lr * 16 + 4 * q;
+            a70 = d2{gpcc_ld_sc1(xd), gpcc_ld_sc1(xd + 1)};
+            a71 = d2{gpcc_ld_sc1(xd + 2), gpcc_ld_sc1(xd + 3)};
+        }
+        if (issued < ch) {
+            if (lane == 0 && okw) okw = gpcc_wait_ge(&colflag[ch], 4u, abortw, 0x100u + ch) ? 1 : 0;
+            okw = __builtin_amdgcn_readfirstlane(okw);
+            // (the last column block arrives as S7 -- before its product with inv(D_7)^T, gpcc_chain_trsmq -- in the step's published area)
+            const double *src = (ch == 7) ? xprev + GPCC_XIMG_ELEMS : Lt + ch * 2048;
+            if (okw) gpcc_dma_piece2_sc1(gpcc_uniform_ptr(src + wave * 256), (unsigned)lane * 16u, smem_addr + (unsigned)(((ch & 1) * 2048) * 8 + wave * 2048));
+            issued = ch;
+        }
         if (tr && ch == 7 && tid == 0) tr[7] = wall_clock64();   // header word 7: the last column block of L(k,k-1) seen
         const int so = (ch & 1) * 2048;
-        if (okw) gpcc_dma_piece2_sc1(gpcc_uniform_ptr(Lt + ch * 2048 + wave * 256), (unsigned)lane * 16u, smem_addr + (unsigned)(so * 8 + wave * 2048));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ch == 7) {
+            // L_7 = S7 inv(D_7)^T: every wave finishes the 16 rows it has copied itself (no barrier in between) the moment inv(D_7) of the
+            // step before is there (requested above) -- V = inv(D_7) S7^T in the result layout [column][row], written back in the chunk's own layout
+            const d2 a0 = a70, a1 = a71;
+            const d2 b0 = *(const d2 *)(p0 + so + wave * 256), b1 = *(const d2 *)(p1 + so + wave * 256);
+            d4 V = {0.0, 0.0, 0.0, 0.0};
+            V = P::mfma(a0[0], b0[0], V);
+            V = P::mfma(a0[1], b0[1], V);
+            V = P::mfma(a1[0], b1[0], V);
+            V = P::mfma(a1[1], b1[1], V);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cc = P::crow(q, r);
+                smem[so + (wave * 16 + lr) * 16 + (((cc >> 1) ^ sw) * 2) + (cc & 1)] = V[r];
+            }
+        }
         if (!__syncthreads_and(okw)) return false;
+        if (ch < 7) {
+            const int nxt = __builtin_amdgcn_readfirstlane((int)peek);
+            if (nxt >= 4) {   // (every reader of stage (ch + 1) & 1 -- block ch - 1 -- is behind the barrier above)
+                const double *src = (ch + 1 == 7) ? xprev + GPCC_XIMG_ELEMS : Lt + (ch + 1) * 2048;
+                gpcc_dma_piece2_sc1(gpcc_uniform_ptr(src + wave * 256), (unsigned)lane * 16u, smem_addr + (unsigned)((((ch + 1) & 1) * 2048) * 8 + wave * 2048));
+                issued = ch + 1;
+            }
+            if (ch < 6 && lane == 0) peek = gpcc_flag_ld(&colflag[ch + 2]);
+        }
         d2 aA[2], aB[2];
         aA[0] = *(const d2 *)(p0 + so + RA * 16 * 16);
         aA[1] = *(const d2 *)(p1 + so + RA * 16 * 16);
@@ -581,21 +590,22 @@ __device__ __forceinline__ void gpcc_chain_role(const GpccCtx &c, const GpccGrou
                 }
             }
         } else {
-            if (tid == 0) ctl[0] = gpcc_wait_ge(&fl.ver[gpcc_tile_idx(k, k)], (unsigned)(k - 1), fl.abortw, 0x200u) ? 1 : 0;
+            if (tid == 0) ctl[0] = gpcc_wait_ge(&fl.ver[gpcc_tile_idx(k, k)], 4u * (unsigned)(k - 1), fl.abortw, 0x200u) ? 1 : 0;
             __syncthreads();
             if (!ctl[0]) return;
             const double *Lt = tiles + gpcc_tile_off(k, k - 1);
             const unsigned *cf = fl.colflag + 8 * (k - 1);
+            const double *xprev = a.ximg + ((long)m * c.nt + k - 1) * GPCC_XIMG_STRIDE;   // what step k - 1 published
             bool ok;
             switch (wave) {
-            case 0: ok = gpcc_chain_syrk_wave<7, 0, 5, 0, 0, 0>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane, tr); break;
-            case 1: ok = gpcc_chain_syrk_wave<6, 0, 5, 0, 0, 0>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane, tr); break;
-            case 2: ok = gpcc_chain_syrk_wave<5, 0, 5, 0, 0, 0>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane, tr); break;
-            case 3: ok = gpcc_chain_syrk_wave<4, 0, 5, 0, 0, 0>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane, tr); break;
-            case 4: ok = gpcc_chain_syrk_wave<7, 5, 3, 0, 0, 1>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane, tr); break;
-            case 5: ok = gpcc_chain_syrk_wave<6, 5, 2, 1, 0, 2>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane, tr); break;
-            case 6: ok = gpcc_chain_syrk_wave<5, 5, 1, 2, 0, 3>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane, tr); break;
-            default: ok = gpcc_chain_syrk_wave<3, 0, 4, 0, 0, 0>(Tt, Lt, cf, fl.abortw, smem, ctl, tid, lane, tr); break;
+            case 0: ok = gpcc_chain_syrk_wave<7, 0, 5, 0, 0, 0>(Tt, Lt, xprev, cf, &fl.xrow[k - 1], fl.abortw, smem, ctl, tid, lane, tr); break;
+            case 1: ok = gpcc_chain_syrk_wave<6, 0, 5, 0, 0, 0>(Tt, Lt, xprev, cf, &fl.xrow[k - 1], fl.abortw, smem, ctl, tid, lane, tr); break;
+            case 2: ok = gpcc_chain_syrk_wave<5, 0, 5, 0, 0, 0>(Tt, Lt, xprev, cf, &fl.xrow[k - 1], fl.abortw, smem, ctl, tid, lane, tr); break;
+            case 3: ok = gpcc_chain_syrk_wave<4, 0, 5, 0, 0, 0>(Tt, Lt, xprev, cf, &fl.xrow[k - 1], fl.abortw, smem, ctl, tid, lane, tr); break;
+            case 4: ok = gpcc_chain_syrk_wave<7, 5, 3, 0, 0, 1>(Tt, Lt, xprev, cf, &fl.xrow[k - 1], fl.abortw, smem, ctl, tid, lane, tr); break;
+            case 5: ok = gpcc_chain_syrk_wave<6, 5, 2, 1, 0, 2>(Tt, Lt, xprev, cf, &fl.xrow[k - 1], fl.abortw, smem, ctl, tid, lane, tr); break;
+            case 6: ok = gpcc_chain_syrk_wave<5, 5, 1, 2, 0, 3>(Tt, Lt, xprev, cf, &fl.xrow[k - 1], fl.abortw, smem, ctl, tid, lane, tr); break;
+            default: ok = gpcc_chain_syrk_wave<3, 0, 4, 0, 0, 0>(Tt, Lt, xprev, cf, &fl.xrow[k - 1], fl.abortw, smem, ctl, tid, lane, tr); break;
             }
             if (!ok) return;
         }
@@ -617,191 +627,193 @@ GPCC_CHAIN_FN bool gpcc_chain_trsmq(const GpccCtx &c, const GpccChainArgs &a, co
                                     const int I, const int qr, double *smem, int *ctl, const int tid, unsigned long long *wt)
 {
     typedef GpccPrec<double> P;
+    constexpr int PLD = 17, PW = 16 * PLD, LLD = GPCC_CHAIN_TLD, LB = 16 * LLD;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 15, q = lane >> 4, sw = gpcc_sw(lr);
-    const int rh = wave & 1, kq = wave >> 1;
+    const int lr = lane & 15, q = lane >> 4;
+    const int rh = wave & 1, kg = (wave >> 1) & 1;
+    const bool worker = wave < 4;           // waves 0-3 multiply, waves 4-7 sum, store and signal
     const bool chain_tile = (I == k + 1);
     double *tiles = (double *)c.tiles + (long)slot * c.slot_stride;
     double *Tt = tiles + gpcc_tile_off(I, k);
     const __amdgpu_buffer_rsrc_t tres = gpcc_rsrc(Tt, GPCC_TILE_ELEMS * 8);
-    const __amdgpu_buffer_rsrc_t xres = gpcc_rsrc(a.ximg + ((long)m * c.nt + k) * GPCC_XIMG_ELEMS, GPCC_XIMG_ELEMS * 8);
-    if (tid == 0) ctl[0] = gpcc_wait_ge(&fl.ver[gpcc_tile_idx(I, k)], (unsigned)k, fl.abortw, 0x300u) ? 1 : 0;
+    double *xk = a.ximg + ((long)m * c.nt + k) * GPCC_XIMG_STRIDE;
+    const __amdgpu_buffer_rsrc_t xres = gpcc_rsrc(xk, GPCC_XIMG_ELEMS * 8);
+    const __amdgpu_buffer_rsrc_t s7res = gpcc_rsrc(xk + GPCC_XIMG_ELEMS, 16 * GPCC_TILE * 8);
+    if (tid == 0) ctl[0] = gpcc_wait_ge(&fl.ver[gpcc_tile_idx(I, k)], 4u * (unsigned)k, fl.abortw, 0x300u) ? 1 : 0;
     __syncthreads();
     if (!ctl[0]) return false;
     if (wt && tid == 0) wt[2] = wall_clock64();
-    // A operand: T(I,k)[32 qr + 16 rh + lr][16 ch + 4 q .. 4 q + 3] for this wave's chunks ch = kq, kq + 4
-    d2 av[2][2];
-    {
-        const int row = 32 * qr + 16 * rh + lr;
-#pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
-            const int ch = kq + 4 * c2;
-            av[c2][0] = gpcc_ld16_sc1(tres, (unsigned)((ch * 2048 + row * 16 + (((2 * q) ^ sw) * 2)) * 8));
-            av[c2][1] = gpcc_ld16_sc1(tres, (unsigned)((ch * 2048 + row * 16 + (((2 * q + 1) ^ sw) * 2)) * 8));
-        }
-    }
-    // reducer threads (waves 0-3): (rh2, row, sp) = 16-byte slot sp (columns 2 sp, 2 sp + 1) of row 16 rh2 + row of the quarter
-    const int rh2 = tid >> 7, rrow = (tid >> 3) & 15, sp = tid & 7;
+    // summing threads (waves 4-7): (rh2, row, sp) = 16-byte slot sp (columns 2 sp, 2 sp + 1) of row 16 rh2 + row of the quarter
+    const int rt = tid & 255, rh2 = rt >> 7, rrow = (rt >> 3) & 15, sp = rt & 7;
     double lv[8][2];
-    int *cdone = ctl + 8;       // [8]: reducer waves that have drained their stores of column block f (LDS counters; the last one signals)
+    int *cdone = ctl + 8;       // [8]: summing waves that have drained their stores of column block f (LDS counters; the last one signals)
     if (tid < 8) cdone[tid] = 0;
-    int seen = 0;               // rows of inv(L_kk) known to be published (uniform)
-    d2 bn[2][2];                // the next row block's operands, requested ahead when that row is known to be out already
-    bool have_next = false;
-    auto load_b = [&](int f, d2 (&b)[2][2]) {
+    int seen = 0;               // row blocks of L_kk known to be published (uniform)
+    double *part = smem;                    // [2][4 waves][16 x PLD]: a wave's contribution to -L_f^T, [column][row]
+    double *lbuf = smem + 2 * 4 * PW;       // [8][2][16 x LLD]: the quarter's finished column blocks, [row][column]: the B operand of the later ones (slot 7: S7)
+    // this wave's elements of T(I,k): row 32 qr + 16 rh + lr, columns 16 f + q + 4 r (only K group 0 starts from T)
+    auto load_t = [&](int f, double (&t)[4]) {
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
-            const int ch = kq + 4 * c2;
-            if (ch <= f) {   // (wave-uniform)
-                const unsigned off = (unsigned)((gpcc_bi(f, ch) + lr * 16 + 4 * q) * 8);
-                b[c2][0] = gpcc_ld16_sc1(xres, off);
-                b[c2][1] = gpcc_ld16_sc1(xres, off + 16u);
+        for (int r = 0; r < 4; ++r) t[r] = gpcc_ld_sc1(Tt + gpcc_elem_off<double>(32 * qr + 16 * rh + lr, 16 * f + q + 4 * r));
+    };
+    // row block f of L_kk as the A operand: blocks (f, j) [column c = lr][k = 4 q ..] for j = kg, kg + 2, .. below f; inv(D_f) [c' = lr][c = q + 4 r]
+    auto load_a = [&](int f, d2 (&av)[4][2], double (&dv)[4], bool with_d) {
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const int j = kg + 2 * c4;
+            if (j < f) {   // (wave-uniform)
+                const unsigned off = (unsigned)((gpcc_bi(f, j) + lr * 16 + 4 * q) * 8);
+                av[c4][0] = gpcc_ld16_sc1(xres, off);
+                av[c4][1] = gpcc_ld16_sc1(xres, off + 16u);
             }
         }
+        if (with_d) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dv[r] = gpcc_ld_sc1(xk + gpcc_bi(f, f) + lr * 16 + q + 4 * r);
+        }
     };
-    // The quarter's own results, row-major 16 x 16 per (column block, row half): the LAST column block is solved from them
-    double *lbuf = smem + 4096;            // [7][2][256]
-    double *sbuf = lbuf + 7 * 2 * 256;     // [2][256]: T_7 - sum_j Lnew_j Lkk[7][j]^T, then the finished block
-    const d2 t7 = (tid < 256) ? gpcc_ld16_sc1(tres, (unsigned)((7 * 2048 + (32 * qr + 16 * rh2 + rrow) * 16 + ((sp ^ gpcc_sw(32 * qr + 16 * rh2 + rrow)) * 2)) * 8))
-                              : d2{0.0, 0.0};   // this reducer's two elements of column block 7 of T(I,k)
-    // column block f of L(I,k), published the moment its four storing waves have drained: each adds to an LDS counter behind its own
-    // wait, the last one adds to the global counter the chain polls (no workgroup barrier in between)
+    // column block f of L(I,k), published once its four storing waves have drained: each adds to an LDS counter behind its own wait, the
+    // last one adds to the global counter the chain polls (no workgroup barrier in between)
     auto signal_block = [&](int f) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         int last = 0;
         if (lane == 0) last = (__hip_atomic_fetch_add(&cdone[f], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 3) ? 1 : 0;
         if (last) gpcc_flag_add(&fl.colflag[8 * k + f], 1u);
     };
-    d2 b7[2][2] = {{{0.0, 0.0}, {0.0, 0.0}}, {{0.0, 0.0}, {0.0, 0.0}}};
     unsigned long long *ht = (a.trace && chain_tile) ? a.trace + ((long)m * c.nt + k) * GPCC_CHAIN_TRACE_WORDS : nullptr;   // header words 4-6 of step k: the LAST of the four quarters of tile (k+1,k) (atomic max)
+    d2 an[4][2];                // the next row block's operands, requested ahead when that row is known to be out already
+    double dn[4], tn[4] = {0.0, 0.0, 0.0, 0.0};
+    bool have_next = false;
+    if (worker && kg == 0) load_t(0, tn);
 #pragma unroll
-    for (int f = 0; f < 7; ++f) {   // (unrolled: lv stays in registers)
-        const int need = f + 1;
-        if (seen < need) {          // caught up with the diagonal step: wait for its next row block (one lane polls; wave 7 is not a reducer)
-            if (tid == GPCC_CHAIN_THREADS - 64) {
-                ctl[0] = gpcc_wait_ge(&fl.xrow[k], (unsigned)need, fl.abortw, 0x310u + f) ? 1 : 0;
-                ctl[3] = (int)gpcc_flag_ld(&fl.xrow[k]);
-            }
-            __syncthreads();
-            if (!ctl[0]) return false;
-            seen = ctl[3];
-            __syncthreads();        // (ctl[3] is rewritten below)
+    for (int f = 0; f < 8; ++f) {   // (unrolled: lv stays in registers)
+        // ---- top of the block: row block f of L_kk and inv(D_f) are out (xrow >= f + 1); the barrier also makes the previous column
+        // block visible in lbuf
+        const bool s7path = (f == 7) && chain_tile;   // the chain tile's last column block leaves as S7, before inv(D_7) is known (below)
+        if (tid == GPCC_CHAIN_THREADS - 64) {   // one lane polls
+            if (s7path) ctl[0] = gpcc_wait_ge(&fl.l7[k], 1u, fl.abortw, 0x318u) ? 1 : 0;
+            else ctl[0] = (seen >= f + 1) ? 1 : (gpcc_wait_ge(&fl.xrow[k], (unsigned)(f + 1), fl.abortw, 0x310u + f) ? 1 : 0);
+            ctl[3] = (int)gpcc_flag_ld(&fl.xrow[k]);
         }
-        if (f == 6) {   // row block 7 of L_kk went out before xrow = 6: fetched here, a column block ahead of its use below
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-                const int j = kq + 4 * c2;
-                if (j < 7) {
-                    const unsigned off = (unsigned)((gpcc_bi(7, j) + lr * 16 + 4 * q) * 8);
-                    b7[c2][0] = gpcc_ld16_sc1(xres, off);
-                    b7[c2][1] = gpcc_ld16_sc1(xres, off + 16u);
-                }
-            }
-        }
-        d2 b[2][2];
-        if (have_next) {
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) { b[c2][0] = bn[c2][0]; b[c2][1] = bn[c2][1]; }
-        } else {
-            load_b(f, b);
-        }
-        have_next = (f < 6) && (seen >= f + 2);
-        if (have_next) load_b(f + 1, bn);
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
-            const int ch = kq + 4 * c2;
-            if (ch <= f) {
-                acc = P::mfma(av[c2][0][0], b[c2][0][0], acc);
-                acc = P::mfma(av[c2][0][1], b[c2][0][1], acc);
-                acc = P::mfma(av[c2][1][0], b[c2][1][0], acc);
-                acc = P::mfma(av[c2][1][1], b[c2][1][1], acc);
-            }
-        }
-        double *part = smem + (f & 1) * 2048 + wave * 256;   // [wave][row][col] of this column block's partials
-#pragma unroll
-        for (int r = 0; r < 4; ++r) part[P::crow(q, r) * 16 + lr] = acc[r];
-        if (tid == GPCC_CHAIN_THREADS - 64) ctl[3] = (int)gpcc_flag_ld(&fl.xrow[k]);   // (a look, not a wait: how far the diagonal step is by now)
-        __syncthreads();
-        seen = ctl[3] > seen ? ctl[3] : seen;
-        if (tid < 256) {
-            const double *pp = smem + (f & 1) * 2048 + rh2 * 256 + rrow * 16 + 2 * sp;
-            d2 sm = *(const d2 *)pp;                      // kq = 0
-            sm += *(const d2 *)(pp + 2 * 256);            // kq = 1 (wave = 2 kq + rh)
-            sm += *(const d2 *)(pp + 4 * 256);
-            sm += *(const d2 *)(pp + 6 * 256);
-            lv[f][0] = sm[0];
-            lv[f][1] = sm[1];
-            *(d2 *)(lbuf + (f * 2 + rh2) * 256 + rrow * 16 + 2 * sp) = sm;
-            const int row = 32 * qr + 16 * rh2 + rrow;
-            gpcc_st16_sc1(tres, (unsigned)((f * 2048 + row * 16 + ((sp ^ gpcc_sw(row)) * 2)) * 8), sm);
-            if (chain_tile) signal_block(f);
-        }
-    }
-    // ---- the LAST column block by forward substitution: L_7 = (T_7 - sum_{j<7} L_j Lkk[7][j]^T) inv(D_7)^T.  Row block 7 of L_kk (out
-    // with row block 5 of the inverse) and inv(D_7) (out right behind the last 16 pivots) are all it needs: it does not wait for the
-    // last row block of the inverse -- 7 dependent block products that the diagonal step would compute when everything else of it is
-    // done (2.5 us + two barriers, and the hop from there) -- and the diagonal step does not compute that row at all any more.
-    {
-        __syncthreads();            // lbuf of column block 6 is complete (and partial buffer 1 free)
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
-            const int j = kq + 4 * c2;
-            if (j < 7) {            // (wave-uniform) A = this quarter's L_j (rows 16 rh ..), B = Lkk[7][j]: [c][k] row-major in ximg
-                const d2 b0 = b7[c2][0], b1 = b7[c2][1];
-                const d2 a0 = *(const d2 *)(lbuf + (j * 2 + rh) * 256 + lr * 16 + 4 * q), a1 = *(const d2 *)(lbuf + (j * 2 + rh) * 256 + lr * 16 + 4 * q + 2);
-                acc = P::mfma(a0[0], b0[0], acc);
-                acc = P::mfma(a0[1], b0[1], acc);
-                acc = P::mfma(a1[0], b1[0], acc);
-                acc = P::mfma(a1[1], b1[1], acc);
-            }
-        }
-        double *part = smem + 2048 + wave * 256;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) part[P::crow(q, r) * 16 + lr] = acc[r];
-        if (ht && tid == 0) atomicMax(&ht[6], (unsigned long long)wall_clock64());   // column block 6 is out, the products with row block 7 of L_kk done
-        if (tid == GPCC_CHAIN_THREADS - 64) ctl[0] = gpcc_wait_ge(&fl.d7[k], 1u, fl.abortw, 0x317u) ? 1 : 0;   // inv(D_7) is out
         __syncthreads();
         if (!ctl[0]) return false;
-        if (ht && tid == 0) atomicMax(&ht[4], (unsigned long long)wall_clock64());
-        d2 bd0 = {0.0, 0.0}, bd1 = {0.0, 0.0};
-        if (wave < 2) {             // (in flight across the reduction below)
-            const unsigned off = (unsigned)((gpcc_bi(7, 7) + lr * 16 + 4 * q) * 8);
-            bd0 = gpcc_ld16_sc1(xres, off);
-            bd1 = gpcc_ld16_sc1(xres, off + 16u);
-        }
-        if (tid < 256) {
-            const double *pp = smem + 2048 + rh2 * 256 + rrow * 16 + 2 * sp;
-            d2 sm = *(const d2 *)pp;
-            sm += *(const d2 *)(pp + 2 * 256);
-            sm += *(const d2 *)(pp + 4 * 256);
-            sm += *(const d2 *)(pp + 6 * 256);
-            *(d2 *)(sbuf + rh2 * 256 + rrow * 16 + 2 * sp) = t7 - sm;
-        }
-        __syncthreads();
-        if (wave < 2) {             // one wave per row half: (16 x 16) times inv(D_7)^T
-            const d2 b0 = bd0, b1 = bd1;
-            const d2 a0 = *(const d2 *)(sbuf + wave * 256 + lr * 16 + 4 * q), a1 = *(const d2 *)(sbuf + wave * 256 + lr * 16 + 4 * q + 2);
-            d4 o = {0.0, 0.0, 0.0, 0.0};
-            o = P::mfma(a0[0], b0[0], o);
-            o = P::mfma(a0[1], b0[1], o);
-            o = P::mfma(a1[0], b1[0], o);
-            o = P::mfma(a1[1], b1[1], o);
-            double *ob = smem + wave * 256;   // (partial buffer 0: free since column block 6 was reduced)
+        seen = ctl[3] > seen ? ctl[3] : seen;
+        if (ht && f == 7 && tid == 0) atomicMax(&ht[4], (unsigned long long)wall_clock64());
+        const bool two = f >= 2;   // K group 1 (column blocks 1, 3, 5) has a share from row block 2 on
+        if (worker) {
+            d2 av[4][2];
+            double dv[4], tv[4];
+            const bool mine = kg == 0 || two;
+            if (mine) {
+                if (have_next) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ob[P::crow(q, r) * 16 + lr] = o[r];
+                    for (int c4 = 0; c4 < 4; ++c4) { av[c4][0] = an[c4][0]; av[c4][1] = an[c4][1]; }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dv[r] = dn[r];
+                } else {
+                    load_a(f, av, dv, !s7path);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tv[r] = tn[r];
+            have_next = (f < 7) && (seen >= f + 2) && !(f == 6 && chain_tile);
+            if (have_next && (kg == 0 || f + 1 >= 2)) load_a(f + 1, an, dn, true);
+            if (f < 7 && kg == 0) load_t(f + 1, tn);
+            if (mine) {
+                // P = sum_j Lkk[f][j] L_j^T - T_f^T  ([column][row]: rows of the quarter along the lanes), then V = inv(D_f) P = -L_f^T:
+                // the first product's result registers ARE the second one's B operand
+                d4 acc, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = (kg == 0) ? -tv[r] : 0.0;
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const int j = kg + 2 * c4;
+                    if (j < f) {
+                        const double *lb = lbuf + (j * 2 + rh) * LB + lr * LLD + 4 * q;
+                        const d2 b0 = *(const d2 *)lb, b1 = *(const d2 *)(lb + 2);
+                        if (c4 & 1) {
+                            acc1 = P::mfma(av[c4][0][0], b0[0], acc1);
+                            acc1 = P::mfma(av[c4][0][1], b0[1], acc1);
+                            acc1 = P::mfma(av[c4][1][0], b1[0], acc1);
+                            acc1 = P::mfma(av[c4][1][1], b1[1], acc1);
+                        } else {
+                            acc = P::mfma(av[c4][0][0], b0[0], acc);
+                            acc = P::mfma(av[c4][0][1], b0[1], acc);
+                            acc = P::mfma(av[c4][1][0], b1[0], acc);
+                            acc = P::mfma(av[c4][1][1], b1[1], acc);
+                        }
+                    }
+                }
+                if (f > 2) acc += acc1;
+                d4 V = {0.0, 0.0, 0.0, 0.0}, V1 = {0.0, 0.0, 0.0, 0.0};
+                if (s7path) {
+                    V = acc;   // (P itself: the product with inv(D_7) is the consumer's)
+                } else {
+                    V = P::mfma(dv[0], acc[0], V);
+                    V1 = P::mfma(dv[1], acc[1], V1);
+                    V = P::mfma(dv[2], acc[2], V);
+                    V1 = P::mfma(dv[3], acc[3], V1);
+                    V += V1;
+                }
+                double *pw = part + ((f & 1) * 4 + wave) * PW;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pw[P::crow(q, r) * PLD + lr] = V[r];
+            }
+        } else if (f > 0 && chain_tile) {
+            signal_block(f - 1);   // (the stores were issued before the barrier above; nothing else for these waves to do until the next one)
+            if (ht && f == 7 && tid == 256) atomicMax(&ht[6], (unsigned long long)wall_clock64());
         }
         __syncthreads();
-        if (tid < 256) {
-            const d2 sm = *(const d2 *)(smem + rh2 * 256 + rrow * 16 + 2 * sp);
-            lv[7][0] = sm[0];
-            lv[7][1] = sm[1];
+        if (!worker) {
+            const double *pp = part + ((f & 1) * 4 + rh2) * PW + (2 * sp) * PLD + rrow;
+            d2 sm = {pp[0], pp[PLD]};                     // K group 0 (wave = 2 kg + rh)
+            if (two) { sm[0] += pp[2 * PW]; sm[1] += pp[2 * PW + PLD]; }
+            sm = -sm;
             const int row = 32 * qr + 16 * rh2 + rrow;
-            gpcc_st16_sc1(tres, (unsigned)((7 * 2048 + row * 16 + ((sp ^ gpcc_sw(row)) * 2)) * 8), sm);
-            if (chain_tile) signal_block(7);
+            if (s7path) {
+                // S7 = T_7 - sum_{j<7} L_j Lkk[7][j]^T goes out in the place of the column block (colflag[7] = "S7 is out"): the chain workgroup
+                // that folds it into tile (k+1,k+1) multiplies it with inv(D_7)^T itself the moment that block is published -- one hand-off
+                // (inv(D_7) -> fold) instead of two (inv(D_7) -> this workgroup -> store, drain, flag -> fold): 3.3 us per diagonal step
+                gpcc_st16_sc1(s7res, (unsigned)((row * 16 + ((sp ^ gpcc_sw(row)) * 2)) * 8), sm);
+                *(d2 *)(lbuf + (7 * 2 + rh2) * LB + rrow * LLD + 2 * sp) = sm;
+                signal_block(7);
+            } else {
+                lv[f][0] = sm[0];
+                lv[f][1] = sm[1];
+                if (f < 7) *(d2 *)(lbuf + (f * 2 + rh2) * LB + rrow * LLD + 2 * sp) = sm;
+                gpcc_st16_sc1(tres, (unsigned)((f * 2048 + row * 16 + ((sp ^ gpcc_sw(row)) * 2)) * 8), sm);
+            }
         }
-        if (ht && tid == 0) atomicMax(&ht[5], (unsigned long long)wall_clock64());
+        if (ht && f == 7 && tid == 256) atomicMax(&ht[5], (unsigned long long)wall_clock64());
+        if (s7path) {
+            // ... and this workgroup's own copy of the block, for the tile: L_7 = S7 inv(D_7)^T, off the chain's path
+            if (tid == GPCC_CHAIN_THREADS - 64) ctl[0] = gpcc_wait_ge(&fl.xrow[k], 8u, fl.abortw, 0x319u) ? 1 : 0;
+            __syncthreads();   // (S7 is complete in lbuf, too)
+            if (!ctl[0]) return false;
+            if (wave < 2) {    // one wave per row half: V = inv(D_7) S7^T = L_7^T
+                const unsigned off = (unsigned)((gpcc_bi(7, 7) + lr * 16 + 4 * q) * 8);
+                const d2 a0 = gpcc_ld16_sc1(xres, off), a1 = gpcc_ld16_sc1(xres, off + 16u);
+                const double *lb = lbuf + (7 * 2 + wave) * LB + lr * LLD + 4 * q;
+                const d2 b0 = *(const d2 *)lb, b1 = *(const d2 *)(lb + 2);
+                d4 V = {0.0, 0.0, 0.0, 0.0};
+                V = P::mfma(a0[0], b0[0], V);
+                V = P::mfma(a0[1], b0[1], V);
+                V = P::mfma(a1[0], b1[0], V);
+                V = P::mfma(a1[1], b1[1], V);
+                double *pw = part + wave * PW;   // (buffer 0: last read for column block 6, two barriers ago)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pw[P::crow(q, r) * PLD + lr] = V[r];
+            }
+            __syncthreads();
+            if (!worker) {
+                const double *pp = part + rh2 * PW + (2 * sp) * PLD + rrow;
+                const d2 sm = {pp[0], pp[PLD]};
+                lv[7][0] = sm[0];
+                lv[7][1] = sm[1];
+                const int row = 32 * qr + 16 * rh2 + rrow;
+                gpcc_st16_sc1(tres, (unsigned)((7 * 2048 + row * 16 + ((sp ^ gpcc_sw(row)) * 2)) * 8), sm);
+            }
+        }
     }
     // w_k (xrow = 9) is what the forward substitution below still needs
     if (tid == GPCC_CHAIN_THREADS - 64) ctl[0] = gpcc_wait_ge(&fl.xrow[k], 9u, fl.abortw, 0x320u) ? 1 : 0;
@@ -809,7 +821,7 @@ GPCC_CHAIN_FN bool gpcc_chain_trsmq(const GpccCtx &c, const GpccChainArgs &a, co
     if (!ctl[0]) return false;
     // forward substitution of logpdf's whitening: z_I[row] -= sum_c L(I,k)[row][c] w_k[c] -- AFTER the last column block is signalled
     // (the chain folds it into tile (k+1,k+1) meanwhile; z_{k+1} is wanted a block step later: gpcc_chain_diag)
-    if (tid < 256) {
+    if (tid >= 256) {
         const double *wp = c.w + (long)slot * c.nrhs * c.Np + k * GPCC_TILE;
         double pr = 0.0;
 #pragma unroll
@@ -847,7 +859,7 @@ GPCC_CHAIN_FN bool gpcc_chain_upd(const GpccCtx &c, const GpccChainFlags &fl, co
     if (tid == 0) {
         bool ok = gpcc_wait_ge(&fl.lcnt[gpcc_tile_idx(I, k)], 4u, fl.abortw, 0x400u);
         ok = ok && gpcc_wait_ge(&fl.lcnt[gpcc_tile_idx(J, k)], 4u, fl.abortw, 0x401u);
-        ok = ok && gpcc_wait_ge(&fl.ver[gpcc_tile_idx(I, J)], (unsigned)k, fl.abortw, 0x402u);
+        ok = ok && gpcc_wait_ge(&fl.ver[gpcc_tile_idx(I, J)], 4u * (unsigned)k, fl.abortw, 0x402u);
         ctl[0] = ok ? 1 : 0;
         if (wt) wt[2] = wall_clock64();
     }
@@ -929,13 +941,101 @@ GPCC_CHAIN_FN bool gpcc_chain_upd(const GpccCtx &c, const GpccChainFlags &fl, co
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) gpcc_flag_st(&fl.ver[gpcc_tile_idx(I, J)], (unsigned)(k + 1));
+    if (tid == 0) gpcc_flag_st(&fl.ver[gpcc_tile_idx(I, J)], 4u * (unsigned)(k + 1));
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// Worker job UPDQ(I, J, k, qr): rows 32 qr .. 32 qr + 31 of the update of tile (I,J) by column k, for the tiles the NEXT step needs at
+// once (groups of one or two evaluations, GpccChainArgs::quarters): local column 0 -- J = k + 1, the tiles the next step solves -- and
+// the diagonal tile (k+2,k+2), which a chain workgroup starts to build when step k is published.  A whole-tile update takes 22 us, and
+// the solves of column k + 1 can only begin behind it: with one job per tile the launch could not step faster than update + solve (22 +
+// 11 us) whatever the chain did.  As four jobs of a quarter of the work on four CUs the tile is there 7 us after column k is, and its
+// solves run beside the diagonal step again.  (Four quarters cost 30 us of CU time instead of 22: with more evaluations in flight the
+// whole-tile job is the better one.)  Wave w: columns 16 w .. 16 w + 15, two row fragments; per chunk of K the 64-row half of L(I,k)
+// that holds the quarter (8 KiB) and all of L(J,k) (16 KiB) by LDS-DMA into a ring of three stages.  ver counts quarters: this job adds
+// 1, a whole-tile update stores 4 (k + 1).
+// ------------------------------------------------------------------------------------------
+GPCC_CHAIN_FN bool gpcc_chain_updq(const GpccCtx &c, const GpccChainFlags &fl, const int slot, const int k, const int I, const int J, const int qr,
+                                   double *smem, int *ctl, const int tid, unsigned long long *wt)
+{
+    typedef GpccPrec<double> P;
+    constexpr int CH = 2048, ST = 3072;   // doubles per chunk of a tile; per ring stage (1024 of A, 2048 of B)
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, q = lane >> 4, sw = gpcc_sw(lr);
+    if (tid == 0) {
+        bool ok = gpcc_wait_ge(&fl.lcnt[gpcc_tile_idx(I, k)], 4u, fl.abortw, 0x500u);
+        ok = ok && gpcc_wait_ge(&fl.lcnt[gpcc_tile_idx(J, k)], 4u, fl.abortw, 0x501u);
+        ok = ok && gpcc_wait_ge(&fl.ver[gpcc_tile_idx(I, J)], 4u * (unsigned)k, fl.abortw, 0x502u);
+        ctl[0] = ok ? 1 : 0;
+        if (wt) wt[2] = wall_clock64();
+    }
+    __syncthreads();
+    if (!ctl[0]) return false;
+    double *tiles = (double *)c.tiles + (long)slot * c.slot_stride;
+    const double *gA = (const double *)gpcc_uniform_ptr(tiles + gpcc_tile_off(I, k) + (qr >> 1) * 1024), *gB = (const double *)gpcc_uniform_ptr(tiles + gpcc_tile_off(J, k));
+    double *Tt = tiles + gpcc_tile_off(I, J);
+    const __amdgpu_buffer_rsrc_t tres = gpcc_rsrc(Tt, GPCC_TILE_ELEMS * 8);
+    const unsigned smem_addr = gpcc_lds_addr(smem);
+    const unsigned voff = (unsigned)lane * 16u;
+    auto dma = [&](int ch) {   // three 1 KiB pieces per wave
+        const unsigned st = smem_addr + (unsigned)((ch % 3) * ST * 8);
+        gpcc_dma_piece1_sc1(gpcc_uniform_ptr(gA + (long)ch * CH + wave * 128), voff, st + wave * 1024);
+        gpcc_dma_piece2_sc1(gpcc_uniform_ptr(gB + (long)ch * CH + wave * 256), voff, st + 8192 + wave * 2048);
+    };
+    dma(0);
+    dma(1);
+    d4 acc[2];
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[fm][r] = -gpcc_ld_sc1(Tt + gpcc_elem_off<double>(32 * qr + fm * 16 + P::crow(q, r), 16 * wave + lr));
+    const double *pa0 = smem + ((qr & 1) * 32 + lr) * 16 + (((2 * q) ^ sw) * 2);
+    const double *pa1 = smem + ((qr & 1) * 32 + lr) * 16 + (((2 * q + 1) ^ sw) * 2);
+    const double *pb0 = smem + 1024 + (16 * wave + lr) * 16 + (((2 * q) ^ sw) * 2);
+    const double *pb1 = smem + 1024 + (16 * wave + lr) * 16 + (((2 * q + 1) ^ sw) * 2);
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+        // (the 8 loads of T above are older than every DMA piece still wanted: vmcnt counts them out first)
+        if (ch < 7) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ch + 2 < 8) dma(ch + 2);
+        const int so = (ch % 3) * ST;
+        const d2 b0 = *(const d2 *)(pb0 + so), b1 = *(const d2 *)(pb1 + so);
+#pragma unroll
+        for (int fm = 0; fm < 2; ++fm) {
+            const d2 a0 = *(const d2 *)(pa0 + so + fm * 256), a1 = *(const d2 *)(pa1 + so + fm * 256);
+            acc[fm] = P::mfma(a0[0], b0[0], acc[fm]);
+            acc[fm] = P::mfma(a0[1], b0[1], acc[fm]);
+            acc[fm] = P::mfma(a1[0], b1[0], acc[fm]);
+            acc[fm] = P::mfma(a1[1], b1[1], acc[fm]);
+        }
+    }
+    // out through LDS in the tile's own byte layout: per chunk (= this wave's 16 columns) the quarter's 32 rows are 4 KiB in one piece
+    __syncthreads();
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rl = fm * 16 + P::crow(q, r);
+            smem[wave * 512 + rl * 16 + (((lr / 2) ^ gpcc_sw(rl)) * 2) + (lr % 2)] = -acc[fm][r];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int e = p * GPCC_CHAIN_THREADS + tid, ch = e >> 8, off = e & 255;
+        gpcc_st16_sc1(tres, (unsigned)((ch * CH + 32 * qr * 16 + off * 2) * 8), *(const d2 *)(smem + ch * 512 + off * 2));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) gpcc_flag_add(&fl.ver[gpcc_tile_idx(I, J)], 1u);
     return true;
 }
 
 // per-evaluation jobs of step k (n = nt - k - 1 tile rows below the diagonal tile): 4 n quarter solves + n(n+1)/2 - 1 tile updates (tile
 // (k+1,k+1) belongs to the chain) -- what the host sizes the grid by
-__host__ __device__ __forceinline__ int gpcc_chain_jobs(int n) { return n <= 0 ? 0 : 4 * n + n * (n + 1) / 2 - 1; }
+__host__ __device__ __forceinline__ int gpcc_chain_jobs(int n) { return n <= 0 ? 0 : 4 * n + 3 * (n - 1) + n * (n + 1) / 2 - 1; }
 
 // grid: the chain block range (16 per 8 evaluations: blocks b and b + 8 -- one XCD, as dispatched -- are the two roles of an
 // evaluation) + workers; block 512; LDS GPCC_CHAIN_LDS_BYTES.
@@ -943,7 +1043,7 @@ __global__ __launch_bounds__(GPCC_CHAIN_THREADS, 2) void gpcc_chain_kernel(GpccC
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double *smem = (double *)smem_raw;
-    int *ctl = (int *)(smem_raw + GPCC_CHAIN_LDS_BYTES - 64);
+    int *ctl = (int *)(smem_raw + GPCC_CHAIN_LDS_BYTES - 128);   // 32 words: [0, 8) a job's control words, [8, 16) gpcc_chain_trsmq's counters, [16] a job's quarter
     const int b = blockIdx.x, tid0 = threadIdx.x;
     // the dedicated range: per 8 evaluations 16 blocks for the two chain roles (b, b + 8) and, with helpers, 32 more for the four
     // quarter solves of tile (k+1,k) -- all six workgroups of evaluation m on blocks = m (mod 8): one XCD as dispatched (a speed bonus
@@ -973,8 +1073,9 @@ __global__ __launch_bounds__(GPCC_CHAIN_THREADS, 2) void gpcc_chain_kernel(GpccC
     }
     // ---- worker: jobs in ONE queue order, claimed by a returning atomic add (wait-free); a claimed job waits for its inputs.  The order
     // of the list of "step" k (n = nt - k - 1 tile rows below the diagonal tile; local tile coordinates a = I - k - 1 >= b = J - k - 1):
-    //     URGENT(k)    the 4 n quarter solves of column k (with helpers: without tile (k+1,k)'s); the updates by column k of the tiles next to the diagonal -- (k+2,k+1), (k+2,k+2),
-    //                  (k+3,k+2), ...: what the chain waits for one or two steps later; the rest of local column 0 (the next step's solves);
+    //     URGENT(k)    the 4 n quarter solves of column k (with helpers: without tile (k+1,k)'s); the updates by column k of local column 0
+    //                  -- (k+2.., k+1), the column the next step solves -- in quarters (gpcc_chain_updq); of the tiles next to the diagonal --
+    //                  (k+2,k+2), (k+3,k+2), (k+3,k+3), ...: what the chain and the band wait for one or two steps later;
     //     FAR(k - 1)   the updates by column k - 1 of the other tiles from local column 2 on (the bulk: ~n^2/2 jobs), ONE STEP LATE;
     //     NEAR1(k)     the updates by column k of the rest of local column 1.
     // Every job's inputs are produced by jobs EARLIER in this order or by the chain (the solves of step k need local column 0 of step
@@ -989,10 +1090,11 @@ __global__ __launch_bounds__(GPCC_CHAIN_THREADS, 2) void gpcc_chain_kernel(GpccC
         asm volatile("" : "+v"(tid));   // (per-job opaque copy, as in gpcc_chain_role)
         if (tid == 0) {
             int j = -1;
+            const int qd = a.quarters ? 4 : 1;
             while (ks < c.nt) {
                 const int n = c.nt - ks - 1, np = n + 1;   // np: rows below the diagonal tile of step ks - 1
                 const int nsol = n >= 1 ? 4 * (n - (a.helpers ? 1 : 0)) : 0;   // (with helpers the solves of tile (k+1,k) are not queue jobs)
-                const int urgent = n >= 1 ? nsol + 2 * (n - 1) + (n >= 3 ? n - 2 : 0) : 0;
+                const int urgent = n >= 2 ? nsol + qd * n + (2 * n - 4) : nsol;
                 const int far = (ks >= 1 && np >= 5) ? (np - 4) * (np - 3) / 2 : 0;
                 const int near = n >= 4 ? n - 3 : 0;
                 const int nj = g.cnt * (urgent + far + near);
@@ -1003,24 +1105,26 @@ __global__ __launch_bounds__(GPCC_CHAIN_THREADS, 2) void gpcc_chain_kernel(GpccC
                 }
                 ++ks;
             }
-            int kind = -1, jk = 0, jI = 0, jJ = 0;
+            int kind = -1, jk = 0, jI = 0, jJ = 0, jq = 0;
             if (j >= 0) {
                 const int n = c.nt - ks - 1, np = n + 1;
                 const int nsol = n >= 1 ? 4 * (n - (a.helpers ? 1 : 0)) : 0;
-                const int band = n >= 1 ? nsol + 2 * (n - 1) : 0;
-                const int urgent = band + (n >= 3 ? n - 2 : 0);
+                const int nnext = n >= 2 ? qd * n : 0;
+                const int urgent = n >= 2 ? nsol + nnext + (2 * n - 4) : nsol;
                 const int far = (ks >= 1 && np >= 5) ? (np - 4) * (np - 3) / 2 : 0;
                 int jj = j / g.cnt, ra, rb;
                 if (jj < nsol) {                  // quarter solve (I, ks, q)
-                    kind = 1; jk = ks; jI = ks + 1 + (a.helpers ? 1 : 0) + jj / 4; jJ = jj % 4;
-                } else if (jj < band) {           // next to the diagonal: (k+2,k+1), (k+2,k+2), (k+3,k+2), (k+3,k+3), ...
-                    const int bnd = jj - nsol;
+                    kind = 1; jk = ks; jI = ks + 1 + (a.helpers ? 1 : 0) + jj / 4; jq = jj % 4;
+                } else if (jj < nsol + nnext) {   // what the next step needs at once: local column 0, (k+2.., k+1), then the diagonal tile (k+2,k+2) -- in quarters for small groups
+                    const int u = (jj - nsol) / qd;
+                    kind = a.quarters ? 3 : 2; jk = ks; jq = (jj - nsol) % qd;
+                    jI = (u < n - 1) ? ks + 2 + u : ks + 2;
+                    jJ = (u < n - 1) ? ks + 1 : ks + 2;
+                } else if (jj < urgent) {         // next to the diagonal: (k+3,k+2), (k+3,k+3), (k+4,k+3), ...
+                    const int bnd = jj - nsol - nnext + 2;
                     ra = 1 + bnd / 2;
                     rb = (bnd & 1) ? ra : ra - 1;
                     kind = 2; jk = ks; jI = ks + 1 + ra; jJ = ks + 1 + rb;
-                } else if (jj < urgent) {         // the rest of local column 0 -- the column the NEXT step solves: (k+3.., k+1)
-                    ra = 2 + (jj - band);
-                    kind = 2; jk = ks; jI = ks + 1 + ra; jJ = ks + 1;
                 } else if (jj < urgent + far) {   // the bulk of step ks - 1: local columns rb = 2 .. np - 3, rows ra = rb + 2 .. np - 1
                     int u = jj - urgent;
                     rb = 2;
@@ -1035,10 +1139,12 @@ __global__ __launch_bounds__(GPCC_CHAIN_THREADS, 2) void gpcc_chain_kernel(GpccC
                     kind = 2; jk = ks; jI = ks + 1 + ra; jJ = ks + 2;
                 }
             }
+            if (kind == 1) jJ = jq;   // (a solve's quarter travels in the column slot)
+            ctl[16] = jq;
             ctl[1] = kind; ctl[2] = jk; ctl[5] = (j >= 0) ? j % g.cnt : 0; ctl[6] = jI; ctl[7] = jJ; ctl[3] = ks;
         }
         __syncthreads();
-        const int kind = ctl[1], k = ctl[2], m = ctl[5], jI = ctl[6], jJ = ctl[7];
+        const int kind = ctl[1], k = ctl[2], m = ctl[5], jI = ctl[6], jJ = ctl[7], jq = ctl[16];
         ks = ctl[3];
         __syncthreads();   // (ctl is rewritten by the job's own waits)
         if (kind < 0) return;
@@ -1056,6 +1162,7 @@ __global__ __launch_bounds__(GPCC_CHAIN_THREADS, 2) void gpcc_chain_kernel(GpccC
         }
         bool ok;
         if (kind == 1) ok = gpcc_chain_trsmq(c, a, fl, m, slot, k, jI, jJ, smem, ctl, tid, wt);
+        else if (kind == 3) ok = gpcc_chain_updq(c, fl, slot, k, jI, jJ, jq, smem, ctl, tid, wt);
         else ok = gpcc_chain_upd(c, fl, slot, k, jI, jJ, smem, ctl, tid, wt);
         if (!ok) return;
         if (wt && tid == 0) wt[3] = wall_clock64();

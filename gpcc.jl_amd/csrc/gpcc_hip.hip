@@ -123,6 +123,9 @@ struct gpcc_handle_s {
     int fused_small_max = 12;  // groups of at most this many evaluations run gpcc_small_step (update + next diagonal step in one launch)
     int chain_max = 12;        // option "chain_max": ... or, fp64 handles, as ONE persistent launch (gpcc_chain.hip.h); 0 = never
     std::atomic<long> chain_count{0};   // evaluations that took the persistent launch so far ("chain_count")
+    long chain_work_max = 3072; // option "chain_work_max": ... and at most this many evaluations x tile-steps^2 (12 at N <= 2048, 3 at N = 4096: above, the
+                                // launch-per-step path is the faster one -- profiles/r05/latency_small_batches.log)
+    int chain_quarters_max = 2; // option "chain_quarters_max": groups of at most this many evaluations update the tiles the next step needs at once in quarter-tile jobs
     int chain_helpers_max = 6; // option "chain_helpers_max": groups of at most this many evaluations give each evaluation four more dedicated workgroups
                                // (the quarter solves of the tile below the diagonal run beside every diagonal step instead of being queue jobs)
     int chain_trace = 0;       // option "chain_trace": the chain workgroups stamp their phases (gpcc_chain_trace; tools/chain_trace.py)
@@ -495,6 +498,12 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
     } else if (!strcmp(key, "chain_max")) {
         if (v < 0 || v > GPCC_CHAIN_MAX_EVALS) return fail(h, GPCC_ERR_ARGUMENT, "chain_max must be in [0,%d]", GPCC_CHAIN_MAX_EVALS);
         h->chain_max = (int)v;
+    } else if (!strcmp(key, "chain_work_max")) {
+        if (v < 0) return fail(h, GPCC_ERR_ARGUMENT, "chain_work_max must be >= 0");
+        h->chain_work_max = (long)v;
+    } else if (!strcmp(key, "chain_quarters_max")) {
+        if (v < 0 || v > GPCC_CHAIN_MAX_EVALS) return fail(h, GPCC_ERR_ARGUMENT, "chain_quarters_max must be in [0,%d]", GPCC_CHAIN_MAX_EVALS);
+        h->chain_quarters_max = (int)v;
     } else if (!strcmp(key, "chain_helpers_max")) {
         if (v < 0 || v > GPCC_CHAIN_MAX_EVALS) return fail(h, GPCC_ERR_ARGUMENT, "chain_helpers_max must be in [0,%d]", GPCC_CHAIN_MAX_EVALS);
         h->chain_helpers_max = (int)v;
@@ -572,6 +581,8 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "chain_count")) return h->chain_count;
     if (!strcmp(key, "chain_trace")) return h->chain_trace;
     if (!strcmp(key, "chain_helpers_max")) return h->chain_helpers_max;
+    if (!strcmp(key, "chain_quarters_max")) return h->chain_quarters_max;
+    if (!strcmp(key, "chain_work_max")) return h->chain_work_max;
     if (!strcmp(key, "shared_prefix")) return h->shared_prefix;
     if (!strcmp(key, "share_tiles")) return h->share_tiles;
     if (!strcmp(key, "N")) return h->N;
@@ -665,11 +676,11 @@ static int ensure_chain(gpcc_handle_t h)
     h->d_chain_words = nullptr; h->d_ximg = h->d_stepval = nullptr; h->d_chain_trace = nullptr; h->chain_streams = 0;
     const long ntiles = (long)h->nt * (h->nt + 1) / 2;
     h->chain_qbase = 16 + 2 * ((h->nt + 15) / 16 * 16);   // abort word + trace counter, then the urgent and the bulk queue's counter per step
-    h->chain_ev_words = (int)((10L * h->nt + 2 * ntiles + 3) / 4 * 4);   // xrow, d7, colflag[8] per step; lcnt, ver per tile
+    h->chain_ev_words = (int)((10L * h->nt + 2 * ntiles + 3) / 4 * 4);   // xrow, l7, colflag[8] per step; lcnt, ver per tile
     h->chain_region_words = ((long)h->chain_qbase + (long)GPCC_CHAIN_MAX_EVALS * h->chain_ev_words + 63) / 64 * 64;
     const long S = h->ws_streams, E = GPCC_CHAIN_MAX_EVALS;
     HIPCHK(h, hipMalloc(&h->d_chain_words, sizeof(unsigned) * h->chain_region_words * S));
-    HIPCHK(h, hipMalloc(&h->d_ximg, sizeof(double) * S * E * h->nt * GPCC_XIMG_ELEMS));
+    HIPCHK(h, hipMalloc(&h->d_ximg, sizeof(double) * S * E * h->nt * GPCC_XIMG_STRIDE));
     HIPCHK(h, hipMalloc(&h->d_stepval, sizeof(double) * S * E * h->nt * GPCC_CHAIN_STEPVALS));
     if (h->chain_trace) {
         const size_t tw = (size_t)S * E * h->nt * GPCC_CHAIN_TRACE_WORDS + (size_t)S * 4 * GPCC_CHAIN_WTRACE_CAP;   // chain stamps, then the workers' jobs
@@ -686,9 +697,11 @@ static int ensure_chain(gpcc_handle_t h)
 }
 
 // a group of a few evaluations (one objective(alpha, rho)) on an fp64 handle's own workspace: the persistent launch
-static bool takes_chain(gpcc_handle_t h, const GpccCtx &c, int cnt)
+static bool takes_chain(gpcc_handle_t h, const GpccCtx &c, int cnt, int concurrent = 1)
 {
-    return h->chain_max > 0 && cnt <= h->chain_max && cnt <= GPCC_CHAIN_MAX_EVALS && cnt <= h->right_looking_max && c.nt > 1 && c.nt_fact == c.nt &&
+    // (a half of a split group runs beside the other half on a second stream: the persistent launch has ONE set of flag words per
+    //  workspace stream, and wants the chip to itself)
+    return concurrent <= 1 && h->chain_max > 0 && cnt <= h->chain_max && (long)cnt * c.nt * c.nt <= h->chain_work_max && cnt <= GPCC_CHAIN_MAX_EVALS && cnt <= h->right_looking_max && c.nt > 1 && c.nt_fact == c.nt &&
            !c.share_p && !c.store_l && c.nrhs == 1 && !c.woodbury && h->precision == GPCC_PRECISION_FP64 && c.tiles == (void *)h->d_tiles &&
            h->d_chain_words != nullptr && h->chain_streams == h->ws_streams;
 }
@@ -699,7 +712,7 @@ static GpccChainArgs chain_args(gpcc_handle_t h, const GpccCtx &c, const GpccGro
     const int si = g.slot0 / (h->ws_slots > 0 ? h->ws_slots : 1);
     GpccChainArgs a;
     a.words = h->d_chain_words + (long)si * h->chain_region_words;
-    a.ximg = h->d_ximg + (long)si * GPCC_CHAIN_MAX_EVALS * c.nt * GPCC_XIMG_ELEMS;
+    a.ximg = h->d_ximg + (long)si * GPCC_CHAIN_MAX_EVALS * c.nt * GPCC_XIMG_STRIDE;
     a.stepval = h->d_stepval + (long)si * GPCC_CHAIN_MAX_EVALS * c.nt * GPCC_CHAIN_STEPVALS;
     a.trace = h->d_chain_trace ? h->d_chain_trace + (long)si * GPCC_CHAIN_MAX_EVALS * c.nt * GPCC_CHAIN_TRACE_WORDS : nullptr;
     a.wtrace = h->d_chain_trace ? h->d_chain_trace + (size_t)h->ws_streams * GPCC_CHAIN_MAX_EVALS * c.nt * GPCC_CHAIN_TRACE_WORDS + (size_t)si * 4 * GPCC_CHAIN_WTRACE_CAP : nullptr;
@@ -707,6 +720,7 @@ static GpccChainArgs chain_args(gpcc_handle_t h, const GpccCtx &c, const GpccGro
     a.ev_words = h->chain_ev_words;
     a.qbase = h->chain_qbase;
     a.helpers = (g.cnt <= h->chain_helpers_max) ? 1 : 0;
+    a.quarters = (g.cnt <= h->chain_quarters_max) ? 1 : 0;
     return a;
 }
 
@@ -843,7 +857,7 @@ static int enqueue_group(gpcc_handle_t h, const GpccCtx &c_in, const GpccGroup &
     if (factor && !ext && h->fold_assembly && c.sep && c.nt > 1 && !c.share_p && c.nt_fact == c.nt && !c.store_l) {
         const bool right = g.cnt <= h->right_looking_max;
         if (takes_fused_solve(h, c, g.cnt, concurrent)) c.fold = 1;
-        else if (!(right && (g.cnt <= h->fused_small_max || takes_chain(h, c, g.cnt)))) c.fold = 2;   // (not the few-evaluation paths)
+        else if (!(right && (g.cnt <= h->fused_small_max || takes_chain(h, c, g.cnt, concurrent)))) c.fold = 2;   // (not the few-evaluation paths)
         // tile rows that straddle two bands or hold padding: the MIXED instantiations (a handle without such rows keeps the leaner ones)
         c.fold_mixed = (c.fold && (h->mixed_rows || c.kernel_id == 1)) ? 1 : 0;
     }
@@ -857,7 +871,7 @@ static int enqueue_group(gpcc_handle_t h, const GpccCtx &c_in, const GpccGroup &
         default: gpcc_sep_points<3><<<grid, GPCC_TILE, 0, s>>>(c, g); break;
         }
     }
-    if (factor && !ext && !single && takes_chain(h, c, g.cnt)) {   // the assembly zeroes the flag words of the persistent launch that follows
+    if (factor && !ext && !single && takes_chain(h, c, g.cnt, concurrent)) {   // the assembly zeroes the flag words of the persistent launch that follows
         const GpccChainArgs ca = chain_args(h, c, g);
         c.chain_words = ca.words; c.chain_qbase = ca.qbase; c.chain_ev_words = ca.ev_words;
     }
@@ -901,7 +915,7 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
     // small groups (the single objective(alpha, rho) call): right-looking, many short jobs per step
     const bool right = (g.cnt <= h->right_looking_max) && (c.nt_fact == c.nt) && !c.share_p;
     const int p = c.share_p;   // shared prefix: steps k < p only involve the leader's rows < p and everyone's rows >= p
-    if (sizeof(T) == 8 && right && takes_chain(h, c, g.cnt)) {
+    if (sizeof(T) == 8 && right && takes_chain(h, c, g.cnt, concurrent)) {
         // a few evaluations on an fp64 handle: ONE persistent launch -- two chain workgroups per evaluation, everybody else pulls jobs
         // (gpcc_chain.hip.h)
         ProfScope pr(h, GPCC_PROF_SMALL_STEP, s);

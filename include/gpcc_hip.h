@@ -104,8 +104,12 @@ int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms
  *                                     (gpcc_chain: two chain workgroups per evaluation carry diagonal step -> column solve -> next
  *                                     diagonal tile without leaving their CUs, all other CUs pull trailing-update jobs; fp64 handles);
  *                                     0 = the two-launches-per-step path below
+ *   chain_work_max           3072     ... and evaluations x (N/128)^2 at most this (12 evaluations up to N = 2048, 3 at N = 4096: above,
+ *                                     the path below is faster)
  *   chain_helpers_max        6        ... with four more dedicated workgroups per evaluation (the solves of the tile below the diagonal run
  *                                     beside every diagonal step) for groups of at most this many evaluations
+ *   chain_quarters_max       2        ... and the tile updates the next step needs at once as four quarter-tile jobs each, for groups of
+ *                                     at most this many evaluations (latency for CU time: 4 x 7.4 us instead of 22 us per tile)
  *   fused_small_max          12       ... otherwise such groups run gpcc_panel_trsm_rows + gpcc_small_step (2 launches per step)
  *   right_looking_max        12       groups of at most this many evaluations factorise right-looking
  *   fused_solve              1        larger groups: panel solve inside the update kernel (gpcc_syrk_diag + gpcc_update_solve);

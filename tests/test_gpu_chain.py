@@ -57,7 +57,8 @@ def test_chain_vs_oracle_and_launch_per_step_path(gp, oracle, Nl, kname, mb):
     ref, rinfo = oracle.loglik_batch(kname, t, y, s, delays[:nref], alpha[:nref], rho[:nref], mb, nthreads=8)
     assert (rinfo == 0).all()
     with gp.Objective(t, y, s, kname, marginalise_b=mb, slots_per_stream=16) as obj:
-        assert obj.get_option("chain_max") == 12
+        assert obj.get_option("chain_max") == 12 and obj.get_option("chain_work_max") == 3072
+        obj.set_option("chain_work_max", 1 << 30)   # (the kernel itself is under test: every group size takes it)
         out = {}
         for m in (1, 2, 5, 12):
             before = obj.get_option("chain_count")
@@ -142,6 +143,28 @@ def test_chain_is_fp64_only_and_other_paths_unchanged(gp, oracle):
         assert np.array_equal(K, K.T)
         Lf, finfo = obj.factor(d[0], alpha, rho)
         assert finfo == 0 and obj.get_option("chain_count") == 12
+
+
+def test_chain_default_policy(gp):
+    """Which groups take the persistent launch by default: at most chain_max = 12 evaluations AND evaluations x (N/128)^2 <= chain_work_max
+    = 3072 -- 3 evaluations at N = 4096, 12 at N = 2048 (profiles/r05/latency_small_batches.log: above, the launch-per-step path is faster)."""
+    from gpcc_amd import synthetic
+    for Nb, takes, not_any_more in ((2048, 3, 4), (1024, 12, 13)):
+        t, y, s, _ = synthetic.simulate_lightcurves([Nb, Nb], seed=5)
+        alpha, rho = synthetic.default_hyperparameters(y)
+        with gp.Objective(t, y, s, "matern32", slots_per_stream=16) as obj:
+            for M, expect in ((takes, takes), (not_any_more, 0)):
+                dd = np.stack([np.zeros(M), np.linspace(0, 3, M)], 1)
+                before = obj.get_option("chain_count")
+                ll, info = obj.loglik_batch(dd, np.tile(alpha, (M, 1)), np.full(M, rho))
+                assert (info == 0).all() and obj.get_option("chain_count") - before == expect
+            if Nb == 2048:   # 6 evaluations at N = 4096 run as two halves of 3 on two streams: NOT two persistent launches side by side
+                dd = np.stack([np.zeros(6), np.linspace(0, 3, 6)], 1)
+                before = obj.get_option("chain_count")
+                ll6, info = obj.loglik_batch(dd, np.tile(alpha, (6, 1)), np.full(6, rho))
+                assert (info == 0).all() and obj.get_option("chain_count") == before
+                ll3, _ = obj.loglik_batch(dd[:3], np.tile(alpha, (3, 1)), np.full(3, rho))
+                assert obj.get_option("chain_count") == before + 3 and _rel(ll3, ll6[:3]) <= 1e-11
 
 
 def test_chain_many_calls_and_two_streams(gp):

@@ -61,7 +61,7 @@ with gpcc_amd.Objective(t, y, s, "matern32", slots_per_stream=16) as obj:
     jt = obj.chain_jobs_trace()
     if len(jt):
         print("== workers: %d jobs stamped (whole group)" % len(jt))
-        for kind, name in ((1, "quarter-tile solve"), (2, "tile update")):
+        for kind, name in ((1, "quarter-tile solve"), (2, "tile update"), (3, "quarter-tile update")):
             r = jt[jt[:, 0] == kind]
             if len(r):
                 wait, run = r[:, 4] - r[:, 3], r[:, 5] - r[:, 4]
@@ -76,7 +76,7 @@ with gpcc_amd.Objective(t, y, s, "matern32", slots_per_stream=16) as obj:
             print("   update of (k,k-1) by column k-2 done | update of (k,k) by column k-2 done | image of tile (k,k) complete")
             for k in range(2, min(nt, 14)):
                 sol = jt[(jt[:, 0] == 1) & (jt[:, 1] == k - 1) & (jt[:, 2] // 1024 == k)]
-                u1 = jt[(jt[:, 0] == 2) & (jt[:, 1] == k - 2) & (jt[:, 2] == k * 1024 + k - 1)]
+                u1 = jt[(jt[:, 0] == 3) & (jt[:, 1] == k - 2) & (jt[:, 2] // 1024 == k)]   # the four quarter updates of tile (k,k-1)
                 u2 = jt[(jt[:, 0] == 2) & (jt[:, 1] == k - 2) & (jt[:, 2] == k * 1024 + k)]
                 f = lambda r, c: ("%8.1f" % r[:, c].max()) if len(r) else "       -"
                 print("   k=%2d: %8.1f | %s / %s / %s | %s | %s | %8.1f" % (k, tr[k - 1, 2], f(sol, 3), f(sol, 4), f(sol, 5), f(u1, 5), f(u2, 5), tr[k, 1]))
