@@ -110,7 +110,7 @@ int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms
  *                                     beside every diagonal step) for groups of at most this many evaluations
  *   chain_quarters_max       2        ... and the tile updates the next step needs at once as four quarter-tile jobs each, for groups of
  *                                     at most this many evaluations (latency for CU time: 4 x 7.4 us instead of 22 us per tile)
- *   fused_small_max          12       ... otherwise such groups run gpcc_panel_trsm_rows + gpcc_small_step (2 launches per step)
+ *   fused_small_max          12       ... otherwise such groups run the kernels gpcc_panel_trsm_rows and gpcc_small_step: 2 launches per step
  *   right_looking_max        12       groups of at most this many evaluations factorise right-looking
  *   fused_solve              1        larger groups: panel solve inside the update kernel (gpcc_syrk_diag + gpcc_update_solve);
  *                                     0 = the three-kernel path (gpcc_panel_update, gpcc_diag_factor, gpcc_panel_trsm) everywhere
@@ -122,7 +122,8 @@ int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms
  *   hybrid_tail              1        three-kernel groups finish right-looking once their trailing matrices fit hybrid_mall_mb
  *   hybrid_mall_mb           400      ... that budget (MB; the Infinity Cache is 256 MiB)
  *   hybrid_occ               384      ... and only steps with fewer left-looking jobs than this become right-looking
- *   split_min / split_max    24 / 240 a group of split_min .. split_max evaluations runs as two halves on two streams (0 = never)
+ *   split_min                24       a group of split_min .. split_max evaluations runs as two halves on two streams (0 = never)
+ *   split_max                240      (see split_min)
  *   split_nt_min             12       ... at N > 128 (split_nt_min - 1)
  *   split_small              1        ... and the smaller groups for which that was measured to pay
  *   shared_prefix            1        0 off; 1: gpcc_loglik_batch detects a fixed-hyper-parameter delay sweep (README.md:172-174) and
