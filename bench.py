@@ -96,7 +96,7 @@ def gpu_state(index=0):
 
 
 def small_executed_ops(N, kernel):
-    """Double-precision pipe work one small-N evaluation EXECUTES (flops; an fma = 2), by source -- the count behind DESIGN.md 4.10's
+    """Double-precision pipe work one small-N evaluation EXECUTES (flops; an fma = 2), by source -- the count behind DESIGN.md 4.6's
     cycle budget.  NB = blocks of the matrix bordered by the right-hand side.  MFMA: row J of the row-wise Cholesky applies J
     finished rows to NB - J blocks and multiplies NB - J - 1 blocks by -inv(L_D): 4 v_mfma_f64_16x16x4_f64 = 8192 flops per block
     product.  Elements (round 4, separable form): NB(NB+1)/2 blocks x 256 elements x (2 mul + min + distance + scale + Matern
@@ -240,7 +240,7 @@ def roofline_leg(obj, args, N, L, G, Gtot, elapsed, run_once):
             an, ams = prof["assemble"]
             nt = (N + TILE - 1) // TILE
             esz = 8.0 if args.precision == "fp64" else 4.0
-            # fold_assembly (DESIGN.md 4.1c): the factorisation evaluates the off-diagonal tiles itself; what the assembly launches
+            # fold_assembly (DESIGN.md 4.1): the factorisation evaluates the off-diagonal tiles itself; what the assembly launches
             # still write is the diagonal tiles (+ tile column 0 on the three-kernel path) and 4 N doubles of per-point factors
             folded = (obj.get_option("fold_assembly") == 1 and nt > 1 and G > obj.get_option("fused_small_max")
                       and (args.kernel != "rbf" or (args.precision == "fp32" and obj.get_option("fp32_assemble") == 1)))
@@ -252,7 +252,7 @@ def roofline_leg(obj, args, N, L, G, Gtot, elapsed, run_once):
                                     "tiles_written_per_evaluation": tiles_written,
                                     "launches_counted": "gpcc_sep_points + gpcc_assemble_tiles" if folded else "gpcc_assemble_tiles"}
         else:
-            # what the fp64 pipe EXECUTES per evaluation beside the algorithmic N^3/3 + N^2 (DESIGN.md 4.10): padded MFMA blocks,
+            # what the fp64 pipe EXECUTES per evaluation beside the algorithmic N^3/3 + N^2 (DESIGN.md 4.6): padded MFMA blocks,
             # the element code (exp) and the 16 x 16 pivot steps, all on the same double-precision pipe
             ex_total = sum(executed.values())
             roofline["executed_ops"] = {"per_evaluation_dp_pipe_flops": {k: round(v) for k, v in executed.items()},

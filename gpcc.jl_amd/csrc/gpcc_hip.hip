@@ -142,7 +142,7 @@ struct gpcc_handle_s {
     int fused_solve = 1;     // option "fused_solve": left-looking groups run gpcc_syrk_diag + gpcc_update_solve (2 launches per step)
     int fold_assembly = 1;   // option "fold_assembly": groups of more than fused_small_max evaluations do not assemble the off-diagonal tiles; the job
                              // of the factorisation that reads a tile first (gpcc_update_solve / gpcc_panel_update) evaluates it into its
-                             // accumulators, bit for bit the assembled tile (GpccCtx::fold, DESIGN.md 4.1c)
+                             // accumulators, bit for bit the assembled tile (GpccCtx::fold, DESIGN.md 4.1)
     int hybrid_tail = 1;     // option "hybrid_tail": left-looking groups of the three-kernel path finish RIGHT-looking once their
                              // trailing matrices fit the Infinity Cache and the left-looking steps would leave CUs idle
     int hybrid_mall_mb = 400;   // option "hybrid_mall_mb": budget for the trailing matrices of a group (256 MiB Infinity Cache; measured
@@ -972,7 +972,7 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
     // columns < ks (cnt n(n+1)/2 equal jobs that stream the rows in lock-step through L2), then each step updates the trailing
     // matrix with its one new column -- many short jobs, affordable because ks is chosen so that the trailing matrices of the
     // whole group stay in the Infinity Cache.  Measured and dropped for the same purpose: split-K and stream-K decompositions
-    // of the update with a last-arriver reduction (bitwise deterministic; no gain: DESIGN.md 4.2d).
+    // of the update with a last-arriver reduction (bitwise deterministic; no gain: DESIGN.md 4.3).
     int ks = right ? 0 : c.nt_fact;   // first right-looking step
     if (!right && !p && !g.spread && h->hybrid_tail && c.nt_fact == c.nt && c.nt >= 6) {
         const double tile_mb = GPCC_TILE_ELEMS * sizeof(T) / 1048576.0;
@@ -1020,7 +1020,7 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
         }
     }
     // augmented systems: Schur complement of the rows beyond the factorised columns,
-    // S = C - V^T V with V = L^-1 [cross block]  (DESIGN.md 4.6)
+    // S = C - V^T V with V = L^-1 [cross block]  (DESIGN.md 4.5)
     for (int k = c.nt_fact; k < c.nt; ++k)
         gpcc_panel_update<T, false><<<cnt8 * (c.nt - k), GPCC_GEMM_THREADS, GPCC_GEMM_LDS_BYTES, s>>>(c, g, k, c.nt_fact, 0);
 }

@@ -80,7 +80,7 @@ struct GpccCtx {
     int *sepflag;    // slots x nt     : low byte: b + 1 if tile row I lies inside ONE band b (no padding), else 0;
                      //                  bit 8: all its points are in the range of the separable form (never set for rbf)
     int fold;        // 1: the off-diagonal tiles inside one band pair are NOT assembled -- gpcc_update_solve evaluates their elements
-                     //    into its accumulators (fused left-looking groups; which tiles: gpcc_fold_mode; DESIGN.md 4.1c);
+                     //    into its accumulators (fused left-looking groups; which tiles: gpcc_fold_mode; DESIGN.md 4.1);
                      // 2: the three-kernel path: likewise for tile columns J >= 1, in the first gpcc_panel_update job that touches the tile
     int fold_mixed;  // 1: ... also the tiles of a tile row that straddles two bands or holds padding (gpcc_fold_mode 3) and tiles that
                      //    need the direct evaluation (mode 4: rbf) -- the MIXED ("general") instantiations of the two kernels: the host
@@ -89,7 +89,7 @@ struct GpccCtx {
     const double *yv;                // Np: raw fluxes (only read by explicit 'Y' rows, see band codes)
     const int *band;                 // Np: >= 0 band of a real point; -1 identity padding;
                                      // <= -2 explicit row e = -2-code: e < L: indicator of band e (a column of Q),
-                                     // e == L: the flux vector Y  (rows of the augmented systems, DESIGN.md 4.6)
+                                     // e == L: the flux vector Y  (rows of the augmented systems, DESIGN.md 4.5)
     double sigma_b[GPCC_MAXL];
     long slot_stride;
     int L, N, Np, nt, kernel_id, marginalise_b;
@@ -97,7 +97,7 @@ struct GpccCtx {
     int nrhs;      // 1: R = Y - bbar.  L+1 (woodbury): R = [Q | Y - bbar]
     int share_p;   // > 0: the evaluations of a group share their first share_p tile rows (same band-1 alpha, rho, delay):
                    //      only the group's first slot (the leader) assembles / factorises them, the others read its tiles,
-                   //      inv(L_kk) and W_k for k < share_p -- bitwise the same values they would have computed (DESIGN 4.9)
+                   //      inv(L_kk) and W_k for k < share_p -- bitwise the same values they would have computed (DESIGN 4.8)
     int asm32;     // fp32 tiles: elements of tiles inside one band pair are EVALUATED in fp32 too (option "fp32_assemble")
     int store_l;   // gpcc_diag_factor also writes L_kk back (dense factor export); 0 on the log-likelihood path
     int woodbury;  // 1: the matrix is K0 = delayedCovariance + Sobs only; B = Q Sigma_b Q' enters through the

@@ -976,7 +976,7 @@ def test_handle_lifetimes_leave_no_device_memory_behind(gp):
 @pytest.mark.parametrize("Nl,prec,tol", [([300, 280], "fp64", 1e-11), ([129], "fp64", 1e-11), ([520, 500, 490], "fp64", 1e-11),
                                          ([384, 300], "fp32", 1e-5)])
 def test_fused_solve_path_agrees_with_three_kernel_path(gp, oracle, Nl, prec, tol):
-    """The default left-looking path (gpcc_syrk_diag + gpcc_update_solve: panel solve inside the update, DESIGN 4.2c) against
+    """The default left-looking path (gpcc_syrk_diag + gpcc_update_solve: panel solve inside the update, DESIGN 4.2) against
     the round-1 kernels (update / diagonal / solve as three launches, `fused_solve` = 0) and against the oracle: same
     arithmetic in another summation order.  Group sizes above and below 8 (the job map differs), a ragged last tile, an
     invalid and a non-positive-definite evaluation in the batch."""
