@@ -13,7 +13,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 DEFAULT_LIB_PATH = os.path.join(CSRC, "libgpcc_hip.so")
 LIB_PATH = os.environ.get("GPCC_HIP_LIB") or DEFAULT_LIB_PATH
-_SOURCES = ["gpcc_hip.hip", "gpcc_small_inst.hip", "gpcc_kernels.hip.h", "gpcc_chain.hip.h", "gpcc_small.hip.h", "gpcc_fit.h", "gpcc_transforms.h"]
+_SOURCES = ["gpcc_hip.hip", "gpcc_small_inst.hip", "gpcc_chain_inst.hip", "gpcc_buildinfo.hip", "gpcc_kernels.hip.h", "gpcc_chain.hip.h",
+            "gpcc_chain_args.h", "gpcc_small.hip.h", "gpcc_fit.h", "gpcc_transforms.h"]
+# what each object is compiled from (an object is reused from csrc/_obj while the hash of these files and of its flags stands)
+_DEPS = {
+    "gpcc_hip.hip": ["gpcc_hip.hip", "gpcc_kernels.hip.h", "gpcc_small.hip.h", "gpcc_chain_args.h", "gpcc_fit.h", "gpcc_transforms.h"],
+    "gpcc_chain_inst.hip": ["gpcc_chain_inst.hip", "gpcc_chain.hip.h", "gpcc_chain_args.h", "gpcc_kernels.hip.h"],
+    "gpcc_small_inst.hip": ["gpcc_small_inst.hip", "gpcc_small.hip.h", "gpcc_kernels.hip.h", "gpcc_transforms.h"],
+    "gpcc_buildinfo.hip": ["gpcc_buildinfo.hip"],
+}
 _HEADER = os.path.join(os.path.dirname(_HERE), "include", "gpcc_hip.h")
 
 
@@ -65,25 +73,49 @@ def build(force=False, verbose=False):
     libdir = os.path.join(rocm, "lib")
     if not os.path.isdir(libdir):
         libdir = "/opt/rocm/lib"
-    # Nine objects compiled side by side: the host + tile kernels, and the small-N families once per (family, kernel id)
-    # (as ONE translation unit the library took 7.5 minutes to build; the objects are independent, no device linking).
-    import tempfile
+    # Eleven objects compiled side by side: the host + tile kernels, the persistent few-evaluation kernel, the small-N families once
+    # per (family, kernel id), the build record (as ONE translation unit the library took 7.5 minutes to build; the objects are
+    # independent, no device linking).  Objects are kept in csrc/_obj and reused while their own sources and flags are unchanged.
     from concurrent.futures import ThreadPoolExecutor
     flags = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed", "-Wno-inline-asm", "-c"]
     flags += _defines()     # A/B builds only (tools/ab_*.sh: e.g. -DGPCC_AB_POLY_EXP into GPCC_HIP_LIB; refused for the default path)
     info = build_info_string()
-    flags += ['-DGPCC_BUILD_INFO_STR="%s"' % info]
-    objdir = tempfile.mkdtemp(prefix="gpcc_build_")
-    jobs = [(os.path.join(objdir, "gpcc_hip.o"), [os.path.join(CSRC, "gpcc_hip.hip")])]
+    objdir = os.path.join(CSRC, "_obj") if os.path.realpath(LIB_PATH) == os.path.realpath(DEFAULT_LIB_PATH) else LIB_PATH + ".obj"
+    os.makedirs(objdir, exist_ok=True)
+    jobs = [(os.path.join(objdir, "gpcc_hip.o"), [os.path.join(CSRC, "gpcc_hip.hip")], "gpcc_hip.hip"),
+            (os.path.join(objdir, "gpcc_chain.o"), [os.path.join(CSRC, "gpcc_chain_inst.hip")], "gpcc_chain_inst.hip"),
+            (os.path.join(objdir, "gpcc_buildinfo.o"), ['-DGPCC_BUILD_INFO_STR="%s"' % info, os.path.join(CSRC, "gpcc_buildinfo.hip")], "gpcc_buildinfo.hip")]
     for wide in (1, 0):
         for kid in range(4):
             jobs.append((os.path.join(objdir, "small_%d_%d.o" % (wide, kid)),
-                         ["-DGPCC_INST_WIDE=%d" % wide, "-DGPCC_INST_KID=%d" % kid, os.path.join(CSRC, "gpcc_small_inst.hip")]))
+                         ["-DGPCC_INST_WIDE=%d" % wide, "-DGPCC_INST_KID=%d" % kid, os.path.join(CSRC, "gpcc_small_inst.hip")], "gpcc_small_inst.hip"))
+
+    def object_key(job):
+        h = hashlib.sha256()
+        h.update(" ".join(flags + job[1]).encode())
+        for dep in _DEPS[job[2]]:
+            h.update(dep.encode() + b"\0")
+            with open(os.path.join(CSRC, dep), "rb") as f:
+                h.update(f.read())
+        return h.hexdigest()
+
+    class _Reused:
+        returncode, stdout, stderr = 0, "", ""
 
     def compile_one(job):
-        obj, args = job
+        obj, args, _ = job
         cmd = flags + args + ["-o", obj]
-        return cmd, subprocess.run(cmd, capture_output=True, text=True)
+        key = object_key(job)
+        try:
+            if not force and os.path.exists(obj) and open(obj + ".key").read() == key:
+                return cmd, _Reused()
+        except OSError:
+            pass
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode == 0:
+            with open(obj + ".key", "w") as f:
+                f.write(key)
+        return cmd, res
 
     workers = max(1, min(len(jobs), int(os.environ.get("GPCC_BUILD_JOBS", "0")) or (os.cpu_count() or 4)))
     with ThreadPoolExecutor(workers) as pool:
@@ -97,7 +129,6 @@ def build(force=False, verbose=False):
         elif verbose:
             print(" ".join(cmd))
             print(res.stdout, res.stderr)
-    shutil.rmtree(objdir, ignore_errors=True)
     if failed:      # every failing command with ITS diagnostics (not the link line with one compile's stderr)
         if os.path.exists(tmp):
             os.remove(tmp)

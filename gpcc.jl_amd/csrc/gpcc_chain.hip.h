@@ -1,28 +1,31 @@
 // gpcc_chain.hip.h -- the FEW-EVALUATION path of libgpcc_hip.so (gfx950 / CDNA4 only): ONE persistent launch per group of at most
 // `chain_max` evaluations (default 12) at N >= 384 -- call site 1 of the boundary, a single objective(alpha, rho)
 // (/root/reference/src/gpccfixdelay_marginaliseb.jl:133-141, called one at a time by Optim's Nelder-Mead, :145-153, :209-211).
+// Compiled as its own translation unit (gpcc_chain_inst.hip); the host side sees gpcc_chain_args.h only.
 //
 // Why: one evaluation's blocked Cholesky (cholesky(K), marginaliseb.jl:139) is a serial chain
 //     diag(k) -> solve of tile (k+1,k) -> update of tile (k+1,k+1) -> diag(k+1) -> ...
 // and as launches (gpcc_panel_trsm_rows + gpcc_small_step, 2 per step) every link waits for the previous one to END: 34 us diagonal
-// step + 8 us solve + 8 us update per step, 1.83 ms at N = 4096 with >= 80 % of the CUs idle.  Kernel time, not launch overhead -- so
+// step + 8 us solve + 8 us update per step, 1.8 ms at N = 4096 with >= 80 % of the CUs idle.  Kernel time, not launch overhead -- so
 // moving the same links into one launch would buy nothing.  What this kernel changes is WHEN a link may start:
-//   * the diagonal step publishes inv(L_kk) ROW BLOCK BY ROW BLOCK (16 rows each, as its software pipeline completes them) -- a
-//     column solve consumes row block f the moment it exists, so when the diagonal step ends only the last of eight pieces is left;
+//   * the diagonal step publishes L_kk ROW BLOCK BY ROW BLOCK (16 rows each) and inv(D_f) right behind the 16 pivots of block f -- a
+//     column solve (forward substitution, gpcc_chain_trsmq) finishes column block f the moment they exist, so when the diagonal step
+//     ends only the last of eight pieces is left;
 //   * the solve of tile (k+1,k) (four quarter-tile jobs on four CUs) publishes L(k+1,k) COLUMN BLOCK BY COLUMN BLOCK, and the workgroup
-//     that will run diag(k+1) folds each one into tile (k+1,k+1) as it arrives (held in registers: 36 lower 16x16 blocks);
-//   * two CHAIN workgroups per evaluation alternate: while A runs diag(k), B builds the image of tile (k+1,k+1); when A's last row
-//     block is out, B is ~3 hand-offs (a few us) from its first pivot.
+//     that will run diag(k+1) folds each one into tile (k+1,k+1) as it arrives (held in registers: 36 lower 16x16 blocks); the last
+//     block it finishes itself (S7);
+//   * two CHAIN workgroups per evaluation alternate: while A runs diag(k), B builds the image of tile (k+1,k+1); when A's last
+//     inv(D_7) is out, B is two hand-offs (a few us) from its first pivot.
 // Everything else -- the solves of the other tiles of column k and the right-looking trailing update -- is pulled as JOBS from an
 // in-order queue by all other CUs ("workers"), sequenced by per-tile counters in global memory instead of kernel boundaries.
 //
 // Hand-offs follow /opt/skills/guides (MI355X_MICROARCH.md, inter-workgroup visibility; cdna_hip_programming.md Guideline 16): every
 // byte another workgroup reads is stored `sc1` (write-through), every storing wave drains (`s_waitcnt vmcnt(0)`), the workgroup
-// meets at a barrier, ONE lane signals (an `sc1` flag store or an agent-scope atomic add); a consumer polls with relaxed `sc1` loads
-// from one lane, releases its workgroup through a barrier, and loads the bytes with `sc1` loads only -- register loads
-// (buffer_load_dwordx4 / global_load_dwordx2 ... sc1) and LDS-DMA (global_load_lds_dwordx4 ... sc1).  The LDS-DMA form is not in the
-// guide's table; tools/xcd_probe.hip measured it on the box (consumer L1-warm, uneven load, every word checked:
-// profiles/r05/xcd_probe_handoff_forms_and_hop_prices.log: 0 stale words of 157 M, the plain forms 31 %) -- measured, not an
+// meets at a barrier (or at an LDS counter whose last adder signals), ONE lane signals (an `sc1` flag store or an agent-scope atomic
+// add); a consumer polls with relaxed `sc1` loads from one lane, releases its workgroup through a barrier, and loads the bytes with
+// `sc1` loads only -- register loads (buffer_load_dwordx4 / global_load_dwordx2 ... sc1) and LDS-DMA (global_load_lds_dwordx4 ... sc1).
+// The LDS-DMA form is not in the guide's table; tools/xcd_probe.hip measured it on the box (consumer L1-warm, uneven load, every word
+// checked: profiles/r05/xcd_probe_handoff_forms_and_hop_prices.log: 0 stale words of 157 M, the plain forms 31 %) -- measured, not an
 // architectural guarantee.  A hop costs 0.6 us (flag) to 1.6 us (flag + 16 KiB).
 //
 // No deadlock, whatever is resident: chain workgroups are the lowest block indices (dispatched first); a worker takes jobs in queue
@@ -31,47 +34,16 @@
 // leaves, and the evaluation reports info = GPCC_INFO_TIMEOUT instead of hanging the GPU.
 //
 // Arithmetic: the same tile algorithm as the launch-per-step path (right-looking, 128 x 128 tiles, the 16-wide blocked diagonal
-// step with its explicit inverse, fused forward substitution), other summation orders inside a tile: results agree to ~1e-13.
+// step, fused forward substitution), other summation orders inside a tile: results agree to ~1e-11 relative in the log-likelihood.
 // A non-positive pivot does not stop anything (NaNs flow through, every flag is still published); the first one is reported as
 // `info`, LAPACK-style, like everywhere else.  fp64 handles only (nrhs = 1).
 #pragma once
-#include "gpcc_kernels.hip.h"
-
-#define GPCC_CHAIN_THREADS 512
-#define GPCC_CHAIN_LDS_BYTES (100 * 1024)  /* three 32 KiB operand stages + control words; > 80 KiB on purpose: ONE workgroup per CU -- the pivot chain runs 2-3x slower beside MFMA waves */
-#define GPCC_CHAIN_MAX_EVALS 16
-#define GPCC_CHAIN_SPIN_LIMIT (1u << 22)
-#define GPCC_CHAIN_MAXRHS 4
-#define GPCC_CHAIN_TLD 18
-#define GPCC_XIMG_STRIDE (GPCC_XIMG_ELEMS + 16 * GPCC_TILE)   /* doubles per (evaluation, step): the published blocks of L_kk, then S7 (gpcc_chain_trsmq) */
-#define GPCC_CHAIN_TMP_OFF (GPCC_XIMG_ELEMS + GPCC_CHAIN_MAXRHS * GPCC_TILE + GPCC_TILE + 2)   /* doubles: gpcc_chain_diag's stmp */
-#define GPCC_XIMG_ELEMS (36 * 256)         /* the lower 36 blocks of inv(L_kk), 16 x 16 row-major each */
-#define GPCC_INFO_TIMEOUT (-9)
-#define GPCC_CHAIN_STEPVALS (2 + GPCC_CHAIN_MAXRHS * GPCC_CHAIN_MAXRHS)
-#define GPCC_CHAIN_WTRACE_CAP 32768        /* job stamps kept per launch */
-#define GPCC_CHAIN_TRACE_WORDS 80          /* stamps per diagonal step: 3 of the role + 8 per block step */
+#include "gpcc_chain_args.h"
 
 typedef unsigned gpcc_u4 __attribute__((ext_vector_type(4)));
 #ifndef GPCC_CHAIN_FN
 #define GPCC_CHAIN_FN __device__ __forceinline__
 #endif
-
-struct GpccChainArgs {
-    unsigned *words;             // zeroed before every launch: [0] abort word; [16 + k] job counter of step k (k = 0 .. nt - 1); from qbase on, per
-                                 // evaluation (ev_words each):
-                                 //   xrow[nt] | l7[nt] | colflag[nt][8] | lcnt[ntiles] | ver[ntiles]
-    double *ximg;                // evaluations x nt x GPCC_XIMG_STRIDE: row blocks of L_kk and the inv(D_f) as published (block (f, j) at gpcc_bi(f, j), row-major),
-                                 // then S7: the last column block of L(k+1,k) before its product with inv(D_7)^T, in the tile's chunk layout
-    double *stepval;             // evaluations x nt x GPCC_CHAIN_STEPVALS: per diagonal step [sum log L_ii of the block, first bad pivot, W'W]
-    unsigned long long *trace;   // optional (NULL): evaluations x nt x GPCC_CHAIN_TRACE_WORDS wall-clock stamps of the chain (tools/chain_trace.py)
-    unsigned long long *wtrace;  // optional (NULL): wtrace_cap x 4 stamps of the workers' jobs: [kind | step | tile, fetched, dependencies met, done]; words[1] counts
-    int wtrace_cap;
-    int ev_words;                // words per evaluation
-    int qbase;                   // first per-evaluation word
-    int helpers;                 // 1: four more dedicated workgroups per evaluation run the quarter solves of the tile below the diagonal
-                                 //    (few evaluations: latency); 0: those solves are queue jobs like the others (more workers)
-    int quarters;                // 1: the updates the next step needs at once are queue jobs of a quarter tile (gpcc_chain_updq); 0: whole tiles
-};
 
 // ---- agent-scope accesses (all hand-off traffic): relaxed atomics lower to global_load / global_store ... sc1
 __device__ __forceinline__ unsigned gpcc_flag_ld(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1033,9 +1005,6 @@ GPCC_CHAIN_FN bool gpcc_chain_updq(const GpccCtx &c, const GpccChainFlags &fl, c
     return true;
 }
 
-// per-evaluation jobs of step k (n = nt - k - 1 tile rows below the diagonal tile): 4 n quarter solves + n(n+1)/2 - 1 tile updates (tile
-// (k+1,k+1) belongs to the chain) -- what the host sizes the grid by
-__host__ __device__ __forceinline__ int gpcc_chain_jobs(int n) { return n <= 0 ? 0 : 4 * n + 3 * (n - 1) + n * (n + 1) / 2 - 1; }
 
 // grid: the chain block range (16 per 8 evaluations: blocks b and b + 8 -- one XCD, as dispatched -- are the two roles of an
 // evaluation) + workers; block 512; LDS GPCC_CHAIN_LDS_BYTES.

@@ -2,7 +2,7 @@
 // kernels of gpcc_kernels.hip.h.  No CPU fallback: every compute entry needs a HIP device.
 #include "gpcc_kernels.hip.h"
 #include "gpcc_small.hip.h"
-#include "gpcc_chain.hip.h"
+#include "gpcc_chain_args.h"
 #include "gpcc_fit.h"
 
 #include "../../include/gpcc_hip.h"
@@ -263,10 +263,7 @@ static int fail(gpcc_handle_t h, int code, const char *fmt, ...)
 
 extern "C" int gpcc_version(void) { return GPCC_VERSION_NUMBER; }
 
-#ifndef GPCC_BUILD_INFO_STR
-#define GPCC_BUILD_INFO_STR "src=unknown defines=[?]"   /* (a build that did not go through gpcc.jl_amd/build.py) */
-#endif
-extern "C" const char *gpcc_build_info(void) { return GPCC_BUILD_INFO_STR; }
+// gpcc_build_info(): gpcc_buildinfo.hip (its own object: the record changes with every source, this file's object does not)
 
 extern "C" const char *gpcc_last_error(gpcc_handle_t h) { return h ? h->err.c_str() : g_err.c_str(); }
 
@@ -663,7 +660,7 @@ static int set_kernel_attributes(gpcc_handle_t h)
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_trsm<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_GEMM_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_trsm_rows<double>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_TRSM_ROWS_LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_panel_trsm_rows<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_TRSM_ROWS_LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute((const void *)gpcc_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GPCC_CHAIN_LDS_BYTES));
+    HIPCHK(h, gpcc_chain_configure());
     return 0;
 }
 
@@ -927,7 +924,7 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
         if (workers > room) workers = room;
         if (workers < 1) workers = 1;
         const long grid = (dedicated + workers > ncb) ? dedicated + workers : ncb;   // (blocks of the dedicated range without a role work too)
-        gpcc_chain_kernel<<<(unsigned)grid, GPCC_CHAIN_THREADS, GPCC_CHAIN_LDS_BYTES, s>>>(c, g, a);
+        gpcc_chain_launch(c, g, a, (unsigned)grid, s);
         h->chain_count += g.cnt;
         return;
     }

@@ -2674,7 +2674,7 @@ static __global__ __launch_bounds__(256) void gpcc_refine_finish(GpccCtx c, Gpcc
 // dense exports (tests, prediction): a square block of one slot's tiles -> column-major n x n
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void gpcc_export_dense(GpccCtx c, int slot, double *out, int symmetric, int off, int n, double jitter)
+static __global__ void gpcc_export_dense(GpccCtx c, int slot, double *out, int symmetric, int off, int n, double jitter)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)n * n) return;
@@ -2697,7 +2697,7 @@ __global__ void gpcc_export_dense(GpccCtx c, int slot, double *out, int symmetri
 // grid nt*nt, block 256.
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void gpcc_load_dense(GpccCtx c, int slot, const double *dense, int n, const double *resid)
+static __global__ void gpcc_load_dense(GpccCtx c, int slot, const double *dense, int n, const double *resid)
 {
     const int I = blockIdx.x / c.nt, J = blockIdx.x % c.nt;
     if (J > I) return;
@@ -2724,7 +2724,7 @@ __global__ void gpcc_load_dense(GpccCtx c, int slot, const double *dense, int n,
 // (src/delayedCovariance.jl:1-35).  xu/yu arrive already shifted (x - delays[band]).
 // ------------------------------------------------------------------------------------------
 template <int KID>
-__global__ void gpcc_covariance_kernel(long nx, long ny, const double *xu, const double *xs, const double *yu,
+static __global__ void gpcc_covariance_kernel(long nx, long ny, const double *xu, const double *xs, const double *yu,
                                        const double *ys, double rho, double *out)
 {
     __shared__ double sexp[64];   // the table exp (2^(j/64) table + degree-5 polynomial; the refinement pass uses it too, the assembly kept
