@@ -40,6 +40,13 @@
 #pragma once
 #include "gpcc_chain_args.h"
 
+// (kernel-side sizes: not in gpcc_chain_args.h, so that tuning them does not rebuild the host object)
+#define GPCC_CHAIN_THREADS 512
+#define GPCC_CHAIN_LDS_BYTES (129 * 1024)  /* four 32 KiB operand stages + control words; > 80 KiB on purpose: ONE workgroup per CU -- the pivot chain runs 2-3x slower beside MFMA waves */
+#define GPCC_CHAIN_SPIN_LIMIT (1u << 22)
+#define GPCC_CHAIN_TLD 18
+#define GPCC_CHAIN_TMP_OFF (GPCC_XIMG_ELEMS + GPCC_CHAIN_MAXRHS * GPCC_TILE + GPCC_TILE + 2)   /* doubles: gpcc_chain_diag's stmp */
+
 typedef unsigned gpcc_u4 __attribute__((ext_vector_type(4)));
 #ifndef GPCC_CHAIN_FN
 #define GPCC_CHAIN_FN __device__ __forceinline__
@@ -817,7 +824,7 @@ GPCC_CHAIN_FN bool gpcc_chain_trsmq(const GpccCtx &c, const GpccChainArgs &a, co
 
 // ------------------------------------------------------------------------------------------
 // Worker job UPD(I, J, k): the right-looking trailing update T(I,J) -= L(I,k) L(J,k)^T of one tile (8 waves x (32 x 64), operands by
-// LDS-DMA -- sc1 -- into a 3-deep ring, the result out through LDS in the tile's own byte layout as 16-byte sc1 stores), once both
+// LDS-DMA -- sc1 -- into a 4-deep ring, the result out of the registers as 16-byte sc1 stores, whole rows of a chunk per instruction), once both
 // column tiles are complete (lcnt = 4 quarters) and the tile has received
 // column k - 1 (ver = k).
 // ------------------------------------------------------------------------------------------
@@ -828,12 +835,17 @@ GPCC_CHAIN_FN bool gpcc_chain_upd(const GpccCtx &c, const GpccChainFlags &fl, co
     constexpr int CH = 2048;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, q = lane >> 4, sw = gpcc_sw(lr);
-    if (tid == 0) {
-        bool ok = gpcc_wait_ge(&fl.lcnt[gpcc_tile_idx(I, k)], 4u, fl.abortw, 0x400u);
-        ok = ok && gpcc_wait_ge(&fl.lcnt[gpcc_tile_idx(J, k)], 4u, fl.abortw, 0x401u);
-        ok = ok && gpcc_wait_ge(&fl.ver[gpcc_tile_idx(I, J)], 4u * (unsigned)k, fl.abortw, 0x402u);
-        ctl[0] = ok ? 1 : 0;
-        if (wt) wt[2] = wall_clock64();
+    if (tid < 64) {   // the three inputs are polled by three lanes side by side (one after the other: three round trips of 0.6 us when all are there already)
+        bool ok = true;
+        if (tid < 3) {
+            const unsigned *p = (tid == 0) ? &fl.lcnt[gpcc_tile_idx(I, k)] : (tid == 1) ? &fl.lcnt[gpcc_tile_idx(J, k)] : &fl.ver[gpcc_tile_idx(I, J)];
+            ok = gpcc_wait_ge(p, (tid == 2) ? 4u * (unsigned)k : 4u, fl.abortw, 0x400u + (unsigned)tid);
+        }
+        const bool all = __all(ok);
+        if (tid == 0) {
+            ctl[0] = all ? 1 : 0;
+            if (wt) wt[2] = wall_clock64();
+        }
     }
     __syncthreads();
     if (!ctl[0]) return false;
@@ -842,13 +854,14 @@ GPCC_CHAIN_FN bool gpcc_chain_upd(const GpccCtx &c, const GpccChainFlags &fl, co
     double *Tt = tiles + gpcc_tile_off(I, J);
     const __amdgpu_buffer_rsrc_t tres = gpcc_rsrc(Tt, GPCC_TILE_ELEMS * 8);
     const unsigned smem_addr = gpcc_lds_addr(smem);
-    // operands by LDS-DMA (sc1) into a ring of THREE 32 KiB stages, two chunks ahead (one workgroup per CU: nobody else hides the
+    // operands by LDS-DMA (sc1) into a ring of FOUR 32 KiB stages, three chunks ahead (one workgroup per CU: nobody else hides the
     // latency of a read that comes from another XCD's write-through).  The accumulators start at -T(I,J) like everywhere else in this
     // library: forming the product from zero and subtracting it once at the end (the tile prefetched as linear pieces) was measured --
     // no faster, and 20x less accurate on matrices with a large B term (1.3e-11 instead of 6e-13 at N = 4095): the running sum then
     // never shrinks towards the Schur complement
     gpcc_dma_chunk_sc1(gA, gB, smem_addr, wave, lane);
     gpcc_dma_chunk_sc1(gA + CH, gB + CH, smem_addr + 2 * GPCC_CHUNK_BYTES, wave, lane);
+    gpcc_dma_chunk_sc1(gA + 2 * CH, gB + 2 * CH, smem_addr + 4 * GPCC_CHUNK_BYTES, wave, lane);
     d4 acc[2][4];
 #pragma unroll
     for (int fm = 0; fm < 2; ++fm)
@@ -864,11 +877,12 @@ GPCC_CHAIN_FN bool gpcc_chain_upd(const GpccCtx &c, const GpccChainFlags &fl, co
     for (int ch = 0; ch < 8; ++ch) {   // one tile of K: the chunks of L(I,k) and L(J,k)
         // chunk ch has landed (4 DMA instructions per wave and chunk; chunk ch + 1 may still fly); behind the barrier every wave has
         // finished chunk ch - 1, whose stage takes chunk ch + 2
-        if (ch < 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (ch < 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ch < 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (ch + 2 < 8) gpcc_dma_chunk_sc1(gA + (long)(ch + 2) * CH, gB + (long)(ch + 2) * CH, smem_addr + ((ch + 2) % 3) * 2 * GPCC_CHUNK_BYTES, wave, lane);
-        const int so = (ch % 3) * 2 * CH;
+        if (ch + 3 < 8) gpcc_dma_chunk_sc1(gA + (long)(ch + 3) * CH, gB + (long)(ch + 3) * CH, smem_addr + ((ch + 3) % 4) * 2 * GPCC_CHUNK_BYTES, wave, lane);
+        const int so = (ch % 4) * 2 * CH;
         d2 a2[2][2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
@@ -891,25 +905,27 @@ GPCC_CHAIN_FN bool gpcc_chain_upd(const GpccCtx &c, const GpccChainFlags &fl, co
                     for (int f = 0; f < 2; ++f) acc[fm][2 * h + f] = P::mfma(a2[fm][s2 / 2][s2 % 2], b[f][s2 / 2][s2 % 2], acc[fm][2 * h + f]);
         }
     }
-    // out through LDS in the tile's own byte layout, rows 64 hv .. 64 hv + 63 at a time (64 KiB), then linear 16-byte sc1 stores
+    // out straight from the registers as 16-byte sc1 stores: a lane pair (columns lr, lr ^ 1) swaps half of its rows, after which the even
+    // lane holds columns (lr, lr + 1) of rows q, q + 4 and the odd lane those of rows q + 8, q + 12 -- one store instruction then
+    // writes eight whole 128-byte rows of a chunk (through LDS, in two halves with four barriers, this took 4.5 of the job's 22 us)
+    {
+        const bool odd = (lr & 1) != 0;
+        const int cs = lr >> 1;
 #pragma unroll
-    for (int hv = 0; hv < 2; ++hv) {
-        __syncthreads();   // (the stages -- resp. the previous half -- have been read)
-        if ((wr >> 1) == hv) {
+        for (int fm = 0; fm < 2; ++fm)
 #pragma unroll
-            for (int fm = 0; fm < 2; ++fm)
+            for (int fn = 0; fn < 4; ++fn) {
+                const int chn = 4 * wc + fn;
 #pragma unroll
-                for (int fn = 0; fn < 4; ++fn)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int rl = (wr & 1) * 32 + fm * 16 + P::crow(q, r), ch = 4 * wc + fn;
-                        smem[ch * 1024 + rl * 16 + (((lr / 2) ^ gpcc_sw(rl)) * 2) + (lr % 2)] = -acc[fm][fn][r];
-                    }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ch = 0; ch < 8; ++ch)   // 512 sixteen-byte pieces per chunk and half: one per thread
-            gpcc_st16_sc1(tres, (unsigned)((ch * CH + hv * 1024 + tid * 2) * 8), *(const d2 *)(smem + ch * 1024 + tid * 2));
+                for (int h = 0; h < 2; ++h) {   // rows r = h (even lane), r = h + 2 (odd lane)
+                    const double mine = odd ? acc[fm][fn][h + 2] : acc[fm][fn][h];
+                    const double give = odd ? acc[fm][fn][h] : acc[fm][fn][h + 2];
+                    const double got = __shfl_xor(give, 1);
+                    const int row = wr * 32 + fm * 16 + P::crow(q, odd ? h + 2 : h);
+                    const d2 v = odd ? d2{-got, -mine} : d2{-mine, -got};
+                    gpcc_st16_sc1(tres, (unsigned)((chn * CH + row * 16 + ((cs ^ gpcc_sw(row)) * 2)) * 8), v);
+                }
+            }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -935,12 +951,17 @@ GPCC_CHAIN_FN bool gpcc_chain_updq(const GpccCtx &c, const GpccChainFlags &fl, c
     constexpr int CH = 2048, ST = 3072;   // doubles per chunk of a tile; per ring stage (1024 of A, 2048 of B)
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, q = lane >> 4, sw = gpcc_sw(lr);
-    if (tid == 0) {
-        bool ok = gpcc_wait_ge(&fl.lcnt[gpcc_tile_idx(I, k)], 4u, fl.abortw, 0x500u);
-        ok = ok && gpcc_wait_ge(&fl.lcnt[gpcc_tile_idx(J, k)], 4u, fl.abortw, 0x501u);
-        ok = ok && gpcc_wait_ge(&fl.ver[gpcc_tile_idx(I, J)], 4u * (unsigned)k, fl.abortw, 0x502u);
-        ctl[0] = ok ? 1 : 0;
-        if (wt) wt[2] = wall_clock64();
+    if (tid < 64) {   // (three lanes poll the three inputs side by side: gpcc_chain_upd)
+        bool ok = true;
+        if (tid < 3) {
+            const unsigned *p = (tid == 0) ? &fl.lcnt[gpcc_tile_idx(I, k)] : (tid == 1) ? &fl.lcnt[gpcc_tile_idx(J, k)] : &fl.ver[gpcc_tile_idx(I, J)];
+            ok = gpcc_wait_ge(p, (tid == 2) ? 4u * (unsigned)k : 4u, fl.abortw, 0x500u + (unsigned)tid);
+        }
+        const bool all = __all(ok);
+        if (tid == 0) {
+            ctl[0] = all ? 1 : 0;
+            if (wt) wt[2] = wall_clock64();
+        }
     }
     __syncthreads();
     if (!ctl[0]) return false;
@@ -984,20 +1005,21 @@ GPCC_CHAIN_FN bool gpcc_chain_updq(const GpccCtx &c, const GpccChainFlags &fl, c
             acc[fm] = P::mfma(a1[1], b1[1], acc[fm]);
         }
     }
-    // out through LDS in the tile's own byte layout: per chunk (= this wave's 16 columns) the quarter's 32 rows are 4 KiB in one piece
-    __syncthreads();
+    // out straight from the registers (gpcc_chain_upd's lane-pair swap): chunk = this wave's 16 columns, whole 128-byte rows per instruction
+    {
+        const bool odd = (lr & 1) != 0;
+        const int cs = lr >> 1;
 #pragma unroll
-    for (int fm = 0; fm < 2; ++fm)
+        for (int fm = 0; fm < 2; ++fm)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rl = fm * 16 + P::crow(q, r);
-            smem[wave * 512 + rl * 16 + (((lr / 2) ^ gpcc_sw(rl)) * 2) + (lr % 2)] = -acc[fm][r];
-        }
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int e = p * GPCC_CHAIN_THREADS + tid, ch = e >> 8, off = e & 255;
-        gpcc_st16_sc1(tres, (unsigned)((ch * CH + 32 * qr * 16 + off * 2) * 8), *(const d2 *)(smem + ch * 512 + off * 2));
+            for (int h = 0; h < 2; ++h) {
+                const double mine = odd ? acc[fm][h + 2] : acc[fm][h];
+                const double give = odd ? acc[fm][h] : acc[fm][h + 2];
+                const double got = __shfl_xor(give, 1);
+                const int row = 32 * qr + fm * 16 + P::crow(q, odd ? h + 2 : h);
+                const d2 v = odd ? d2{-got, -mine} : d2{-mine, -got};
+                gpcc_st16_sc1(tres, (unsigned)((wave * CH + row * 16 + ((cs ^ gpcc_sw(row)) * 2)) * 8), v);
+            }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

@@ -4,14 +4,9 @@
 #include "gpcc_kernels.hip.h"
 
 
-#define GPCC_CHAIN_THREADS 512
-#define GPCC_CHAIN_LDS_BYTES (100 * 1024)  /* three 32 KiB operand stages + control words; > 80 KiB on purpose: ONE workgroup per CU -- the pivot chain runs 2-3x slower beside MFMA waves */
 #define GPCC_CHAIN_MAX_EVALS 16
-#define GPCC_CHAIN_SPIN_LIMIT (1u << 22)
 #define GPCC_CHAIN_MAXRHS 4
-#define GPCC_CHAIN_TLD 18
 #define GPCC_XIMG_STRIDE (GPCC_XIMG_ELEMS + 16 * GPCC_TILE)   /* doubles per (evaluation, step): the published blocks of L_kk, then S7 (gpcc_chain_trsmq) */
-#define GPCC_CHAIN_TMP_OFF (GPCC_XIMG_ELEMS + GPCC_CHAIN_MAXRHS * GPCC_TILE + GPCC_TILE + 2)   /* doubles: gpcc_chain_diag's stmp */
 #define GPCC_XIMG_ELEMS (36 * 256)         /* the lower 36 blocks of inv(L_kk), 16 x 16 row-major each */
 #define GPCC_INFO_TIMEOUT (-9)
 #define GPCC_CHAIN_STEPVALS (2 + GPCC_CHAIN_MAXRHS * GPCC_CHAIN_MAXRHS)

@@ -123,7 +123,7 @@ struct gpcc_handle_s {
     int fused_small_max = 12;  // groups of at most this many evaluations run gpcc_small_step (update + next diagonal step in one launch)
     int chain_max = 12;        // option "chain_max": ... or, fp64 handles, as ONE persistent launch (gpcc_chain.hip.h); 0 = never
     std::atomic<long> chain_count{0};   // evaluations that took the persistent launch so far ("chain_count")
-    long chain_work_max = 3072; // option "chain_work_max": ... and at most this many evaluations x tile-steps^2 (12 at N <= 2048, 3 at N = 4096: above, the
+    long chain_work_max = 4096; // option "chain_work_max": ... and at most this many evaluations x tile-steps^2 (12 at N <= 2048, 4 at N = 4096: above, the
                                 // launch-per-step path is the faster one -- profiles/r05/latency_small_batches.log)
     int chain_quarters_max = 2; // option "chain_quarters_max": groups of at most this many evaluations update the tiles the next step needs at once in quarter-tile jobs
     int chain_helpers_max = 6; // option "chain_helpers_max": groups of at most this many evaluations give each evaluation four more dedicated workgroups

@@ -104,7 +104,7 @@ int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms
  *                                     (gpcc_chain: two chain workgroups per evaluation carry diagonal step -> column solve -> next
  *                                     diagonal tile without leaving their CUs, all other CUs pull trailing-update jobs; fp64 handles);
  *                                     0 = the two-launches-per-step path below
- *   chain_work_max           3072     ... and evaluations x (N/128)^2 at most this (12 evaluations up to N = 2048, 3 at N = 4096: above,
+ *   chain_work_max           4096     ... and evaluations x (N/128)^2 at most this (12 evaluations up to N = 2048, 4 at N = 4096: above,
  *                                     the path below is faster)
  *   chain_helpers_max        6        ... with four more dedicated workgroups per evaluation (the solves of the tile below the diagonal run
  *                                     beside every diagonal step) for groups of at most this many evaluations

@@ -57,7 +57,7 @@ def test_chain_vs_oracle_and_launch_per_step_path(gp, oracle, Nl, kname, mb):
     ref, rinfo = oracle.loglik_batch(kname, t, y, s, delays[:nref], alpha[:nref], rho[:nref], mb, nthreads=8)
     assert (rinfo == 0).all()
     with gp.Objective(t, y, s, kname, marginalise_b=mb, slots_per_stream=16) as obj:
-        assert obj.get_option("chain_max") == 12 and obj.get_option("chain_work_max") == 3072
+        assert obj.get_option("chain_max") == 12 and obj.get_option("chain_work_max") == 4096
         obj.set_option("chain_work_max", 1 << 30)   # (the kernel itself is under test: every group size takes it)
         out = {}
         for m in (1, 2, 5, 12):
@@ -147,9 +147,9 @@ def test_chain_is_fp64_only_and_other_paths_unchanged(gp, oracle):
 
 def test_chain_default_policy(gp):
     """Which groups take the persistent launch by default: at most chain_max = 12 evaluations AND evaluations x (N/128)^2 <= chain_work_max
-    = 3072 -- 3 evaluations at N = 4096, 12 at N = 2048 (profiles/r05/latency_small_batches.log: above, the launch-per-step path is faster)."""
+    = 4096 -- 4 evaluations at N = 4096, 12 at N = 2048 (profiles/r05/latency_small_batches.log: above, the launch-per-step path is faster)."""
     from gpcc_amd import synthetic
-    for Nb, takes, not_any_more in ((2048, 3, 4), (1024, 12, 13)):
+    for Nb, takes, not_any_more in ((2048, 4, 5), (1024, 12, 13)):
         t, y, s, _ = synthetic.simulate_lightcurves([Nb, Nb], seed=5)
         alpha, rho = synthetic.default_hyperparameters(y)
         with gp.Objective(t, y, s, "matern32", slots_per_stream=16) as obj:

@@ -26,6 +26,7 @@ M = args.evals
 d = np.concatenate([np.zeros((M, 1)), np.linspace(0, 20, M)[:, None] * np.ones((1, args.bands - 1))], 1)
 with gpcc_amd.Objective(t, y, s, "matern32", slots_per_stream=16) as obj:
     obj.set_option("chain_trace", 1)
+    obj.set_option("chain_work_max", 1 << 30)   # (whatever the group size: the kernel itself is looked at)
     for _ in range(3):
         ll, info = obj.loglik_batch(d, np.tile(alpha, (M, 1)), np.full(M, rho))
     for m in range(M):

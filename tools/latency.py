@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Latency of small batches through the host-pointer API (call site 1 of the boundary: one objective(alpha, rho),
 marginaliseb.jl:133-141): the persistent launch (chain_max = 12, every group size forced onto it: chain_work_max lifted) against the two-launches-per-step path
-(chain_max = 0).  The default policy picks the persistent launch for M <= 12 and M x (N/128)^2 <= 3072.
+(chain_max = 0).  The default policy picks the persistent launch for M <= 12 and M x (N/128)^2 <= 4096.
   python tools/latency.py [--sizes 512,2048] [--batches 1,2,4,8,12] [--reps 20]"""
 import argparse
 import sys
@@ -27,7 +27,7 @@ for Nb in [int(v) for v in args.sizes.split(",")]:
     for cm in (0, 12):
         with gpcc_amd.Objective(t, y, s, "matern32", slots_per_stream=64) as obj:
             obj.set_option("chain_max", cm)
-            obj.set_option("chain_work_max", 1 << 30)   # (every group up to chain_max: the default policy takes evaluations x (N/128)^2 <= 3072)
+            obj.set_option("chain_work_max", 1 << 30)   # (every group up to chain_max: the default policy takes evaluations x (N/128)^2 <= 4096)
             for M in [int(v) for v in args.batches.split(",")]:
                 d = np.concatenate([np.zeros((M, 1)), np.linspace(0, 20, M)[:, None] * np.ones((1, args.bands - 1))], 1)
                 a = np.tile(alpha, (M, 1))
