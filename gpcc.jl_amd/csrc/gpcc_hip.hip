@@ -815,7 +815,7 @@ struct ProfScope {
 template <bool EXT, typename T>
 static void launch_assemble_t(const GpccCtx &c, const GpccGroup &g, hipStream_t s)
 {
-    dim3 grid(c.nt * c.nt, g.cnt);
+    dim3 grid(c.nt * c.nt, g.cnt, c.chain_words ? 4 : 1);   // (in front of the persistent launch: a row quarter per workgroup)
     switch (c.kernel_id) {
     case 0: gpcc_assemble_tiles<0, EXT, T><<<grid, 256, 0, s>>>(c, g); break;
     case 1: gpcc_assemble_tiles<1, EXT, T><<<grid, 256, 0, s>>>(c, g); break;

@@ -612,6 +612,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 4) void gpcc_assemble_til
     const int I = blockIdx.x / c.nt, J = blockIdx.x % c.nt;
     if (J > I) return;
     const int m = blockIdx.y, slot = g.slot0 + m, tid = threadIdx.x;
+    // gridDim.z = 4 (a few evaluations in front of the persistent launch): a workgroup writes one row quarter -- rows r0 + 32 z of
+    // every thread -- of its tile: four times the workgroups for a launch that would otherwise be 36 .. 528 of them on 256 CUs
+    const int qz = (gridDim.z > 1) ? (int)blockIdx.z : -1;
     const int first_row = (c.share_p && m > 0) ? c.share_p : 0;   // followers of a shared prefix skip the leader's rows
     if (I < first_row) return;
     // fold: this tile is never read from memory -- gpcc_update_solve evaluates it into its accumulators (flags: gpcc_sep_points)
@@ -690,6 +693,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 4) void gpcc_assemble_til
             const float acol = (float)sa[1][0];   // one band per side: one amplitude per side
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                if (qz >= 0 && j != qz) continue;
                 const int r = (tid >> 3) + 32 * j;
                 const double ur = su[0][r];
                 const float amp = (float)sa[0][r] * acol;
@@ -736,6 +740,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 4) void gpcc_assemble_til
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    if (qz >= 0 && j != qz) continue;
                     typename P::v16 v;
 #pragma unroll
                     for (int h = 0; h < P::EP; ++h) v[h] = (T)(gpcc_sep_eval<KID>(ur[j], uc[h], Ar[j], Br[j], Ac[h], Bc[h], kscale) + bt);
@@ -748,7 +753,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 4) void gpcc_assemble_til
         const double acol = sa[1][0];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int r = (tid >> 3) + 32 * j;
+            if (qz >= 0 && j != qz) continue;
+                const int r = (tid >> 3) + 32 * j;
             const double ur = su[0][r], amp = sa[0][r] * acol;
             const int cs = (sp ^ gpcc_sw(r)) * P::EP;
 #pragma unroll
@@ -766,7 +772,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 4) void gpcc_assemble_til
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int r = (tid >> 3) + 32 * j;  // row data stays in registers across the chunks
+        if (qz >= 0 && j != qz) continue;
+                const int r = (tid >> 3) + 32 * j;  // row data stays in registers across the chunks
         const int br = sb[0][r];
         const double ur = su[0][r], ar = sa[0][r], sg = ssig[r];
         const double Ar = (KID != 1) ? sA[0][r] : 0.0, Br = (KID != 1) ? sB[0][r] : 0.0;
