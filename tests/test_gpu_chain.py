@@ -187,3 +187,40 @@ def test_chain_many_calls_and_two_streams(gp):
             v = obj(alpha, rho, [0.0, 2.0])
             first = v if first is None else first
             assert v == first
+
+
+def test_chain_device_pointer_entry_and_concurrent_handles(gp):
+    """The device-pointer entry (gpcc_loglik_batch_device: what one process per GPU calls) with a few evaluations takes the persistent
+    launch on the caller's stream and returns the host-pointer entry's bits; four threads with a handle each -- four persistent launches
+    competing for the CUs, the shape of tools/concurrent_callers.py -- return what a single caller gets, call after call."""
+    import threading
+
+    import torch
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([330, 310], seed=9)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    M = 3
+    dd = np.stack([np.zeros(M), np.linspace(0.5, 4.0, M)], 1)
+    aa, rr = np.tile(alpha, (M, 1)), np.full(M, rho)
+    with gp.Objective(t, y, s, "matern32", slots_per_stream=16) as obj:
+        ll, info = obj.loglik_batch(dd, aa, rr)
+        before = obj.get_option("chain_count")
+        dev = torch.device("cuda:0")
+        out, oinfo = obj.loglik_batch_device(torch.tensor(dd, device=dev), torch.tensor(aa, device=dev), torch.tensor(rr, device=dev))
+        torch.cuda.synchronize()
+        assert obj.get_option("chain_count") == before + M
+        assert np.array_equal(out.cpu().numpy(), ll) and (oinfo.cpu().numpy() == 0).all()
+    ref = ll[0]
+    results = [None] * 4
+
+    def caller(i):
+        with gp.Objective(t, y, s, "matern32", slots_per_stream=16, streams=1) as o:
+            results[i] = [o(alpha, rho, dd[0]) for _ in range(60)]
+
+    th = [threading.Thread(target=caller, args=(i,)) for i in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for r in results:
+        assert r is not None and all(v == ref for v in r)
