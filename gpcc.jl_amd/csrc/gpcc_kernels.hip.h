@@ -1627,7 +1627,9 @@ __device__ __forceinline__ int gpcc_potf2_core(double (&v)[16], double *sr, cons
 #pragma unroll
     for (int cc = 0; cc < 16; ++cc) cn[0][cc] = cn[1][cc] = 0.0;
     double d = gpcc_bcast(v[0], 0), wp = 0.0;
-    int bad = 0;
+    unsigned badm = 0u;   // bit j: pivot j was not positive (resolved once, behind the loop: as a running "first bad pivot" the compiler kept 16
+                          // flags and walked them in ~100 scalar instructions at the end of every block -- on the critical path of every diagonal step)
+    double t1 = 1.0, t2 = 1.0, t3 = 1.0, t4 = 1.0;   // prod 1/sqrt(d_j) as a pairwise tree: 4 multiplications behind the last pivot, not 16
     __builtin_amdgcn_sched_barrier(0);
     // pivot j - 1's update of column cc >= j + 2, one pivot late: v[cc] -= L[l][j-1] L[cc][j-1] = (v[j-1] y y) * (column entry before scaling)
 #define GPCC_POTF2_FILL(k)                                                                                        \
@@ -1640,7 +1642,7 @@ __device__ __forceinline__ int gpcc_potf2_core(double (&v)[16], double *sr, cons
             quad = -d;
             d = 1.0;
         }
-        if (__builtin_amdgcn_fcmp(d, 0.0, 2 /* ordered > */) == 0ull && bad == 0) bad = j + 1;   // (d is the same in every lane: scalar; also catches NaN)
+        badm |= (__builtin_amdgcn_fcmp(d, 0.0, 2 /* ordered > */) == 0ull) ? (1u << j) : 0u;   // (d is the same in every lane: scalar; also catches NaN)
         const double hd = -0.5 * d;
         double y = __builtin_amdgcn_rsq(d);
         // off the chain, while 1/sqrt(d) is on its way: the entries of rows j + 1, j + 2 the NEXT pivot needs (columns j and j + 1 are
@@ -1688,10 +1690,24 @@ __device__ __forceinline__ int gpcc_potf2_core(double (&v)[16], double *sr, cons
         GPCC_POTF2_FILL(11);
         GPCC_POTF2_FILL(12);
         GPCC_POTF2_FILL(13);
-        py *= y;
-        if ((j & 3) == 3) {
-            pe += __builtin_amdgcn_frexp_exp(py);
-            py = __builtin_amdgcn_frexp_mant(py);
+        if ((j & 1) == 0) {
+            t1 = y;
+        } else {
+            const double p1 = t1 * y;
+            if ((j & 3) == 1) {
+                t2 = p1;
+            } else {
+                double p2 = t2 * p1;             // four pivots: mantissa / exponent (no overflow whatever the scale of K)
+                pe += __builtin_amdgcn_frexp_exp(p2);
+                p2 = __builtin_amdgcn_frexp_mant(p2);
+                if ((j & 7) == 3) {
+                    t3 = p2;
+                } else {
+                    const double p3 = t3 * p2;
+                    if (j == 7) t4 = p3;
+                    else py *= t4 * p3;
+                }
+            }
         }
         if (TRACK) {
             const double ratio = skd[j] * (y * y);
@@ -1708,7 +1724,9 @@ __device__ __forceinline__ int gpcc_potf2_core(double (&v)[16], double *sr, cons
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef GPCC_POTF2_FILL
-    return bad;
+    pe += __builtin_amdgcn_frexp_exp(py);
+    py = __builtin_amdgcn_frexp_mant(py);
+    return badm ? (int)__builtin_ctz(badm) + 1 : 0;
 }
 
 // loglik = -(N log 2pi + logdet K)/2 - (Y-bbar)' K^-1 (Y-bbar)/2  (Distributions.logpdf, marginaliseb.jl:139) from
