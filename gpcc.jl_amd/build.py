@@ -14,11 +14,11 @@ CSRC = os.path.join(_HERE, "csrc")
 DEFAULT_LIB_PATH = os.path.join(CSRC, "libgpcc_hip.so")
 LIB_PATH = os.environ.get("GPCC_HIP_LIB") or DEFAULT_LIB_PATH
 _SOURCES = ["gpcc_hip.hip", "gpcc_small_inst.hip", "gpcc_chain_inst.hip", "gpcc_buildinfo.hip", "gpcc_kernels.hip.h", "gpcc_chain.hip.h",
-            "gpcc_chain_args.h", "gpcc_small.hip.h", "gpcc_fit.h", "gpcc_transforms.h"]
+            "gpcc_chain_args.h", "gpcc_chain_queue.h", "gpcc_small.hip.h", "gpcc_fit.h", "gpcc_transforms.h"]
 # what each object is compiled from (an object is reused from csrc/_obj while the hash of these files and of its flags stands)
 _DEPS = {
-    "gpcc_hip.hip": ["gpcc_hip.hip", "gpcc_kernels.hip.h", "gpcc_small.hip.h", "gpcc_chain_args.h", "gpcc_fit.h", "gpcc_transforms.h"],
-    "gpcc_chain_inst.hip": ["gpcc_chain_inst.hip", "gpcc_chain.hip.h", "gpcc_chain_args.h", "gpcc_kernels.hip.h"],
+    "gpcc_hip.hip": ["gpcc_hip.hip", "gpcc_kernels.hip.h", "gpcc_small.hip.h", "gpcc_chain_args.h", "gpcc_chain_queue.h", "gpcc_fit.h", "gpcc_transforms.h"],
+    "gpcc_chain_inst.hip": ["gpcc_chain_inst.hip", "gpcc_chain.hip.h", "gpcc_chain_args.h", "gpcc_chain_queue.h", "gpcc_kernels.hip.h"],
     "gpcc_small_inst.hip": ["gpcc_small_inst.hip", "gpcc_small.hip.h", "gpcc_kernels.hip.h", "gpcc_transforms.h"],
     "gpcc_buildinfo.hip": ["gpcc_buildinfo.hip"],
 }

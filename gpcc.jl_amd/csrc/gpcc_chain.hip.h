@@ -1062,33 +1062,22 @@ __global__ __launch_bounds__(GPCC_CHAIN_THREADS, 2) void gpcc_chain_kernel(GpccC
             return;
         }
     }
-    // ---- worker: jobs in ONE queue order, claimed by a returning atomic add (wait-free); a claimed job waits for its inputs.  The order
-    // of the list of "step" k (n = nt - k - 1 tile rows below the diagonal tile; local tile coordinates a = I - k - 1 >= b = J - k - 1):
-    //     URGENT(k)    the 4 n quarter solves of column k (with helpers: without tile (k+1,k)'s); the updates by column k of local column 0
-    //                  -- (k+2.., k+1), the column the next step solves -- in quarters (gpcc_chain_updq); of the tiles next to the diagonal --
-    //                  (k+2,k+2), (k+3,k+2), (k+3,k+3), ...: what the chain and the band wait for one or two steps later;
-    //     FAR(k - 1)   the updates by column k - 1 of the other tiles from local column 2 on (the bulk: ~n^2/2 jobs), ONE STEP LATE;
-    //     NEAR1(k)     the updates by column k of the rest of local column 1.
-    // Every job's inputs are produced by jobs EARLIER in this order or by the chain (the solves of step k need local column 0 of step
-    // k-1; local column 0 of step k was local column 1 of step k-1 (NEAR1); FAR(k-1) needs step k-1's solves and FAR(k-2) / NEAR1(k-2);
-    // NEAR1(k) was local column 2 of step k-1: FAR(k-1), just in front), so the oldest unfinished job can always run: no deadlock
-    // whatever is resident.  Why the bulk is one step late: in plain step order the urgent jobs of step k were claimed only after every
-    // bulk job of step k - 1 had been -- in the first nt/4 steps that is two rounds of 23 us jobs on 254 CUs, and the chain of a single
-    // evaluation waited 16 us instead of 5 between its diagonal steps (profiles/r05/chain_trace_first_version.log).
+    // ---- worker: jobs in ONE queue order (gpcc_chain_queue.h), claimed by a returning atomic add (wait-free); a claimed job waits for its
+    // inputs.  Every job's inputs are produced by jobs EARLIER in this order or by the chain (the solves of step k need local column 0 of
+    // step k-1; local column 0 of step k was local column 1 of step k-1 (NEAR1); FAR(k-1) needs step k-1's solves and FAR(k-2) /
+    // NEAR1(k-2); NEAR1(k) was local column 2 of step k-1: FAR(k-1), just in front), so the oldest unfinished job can always run: no
+    // deadlock whatever is resident (checked for every size by tests/abi/chain_queue_check.cpp).  Why the bulk is one step late: in plain
+    // step order the urgent jobs of step k were claimed only after every bulk job of step k - 1 had been -- in the first nt/4 steps that is
+    // two rounds of 23 us jobs on 254 CUs, and the chain of a single evaluation waited 16 us instead of 5 between its diagonal steps
+    // (profiles/r05/chain_trace_first_version.log).
     int ks = 0;
     for (;;) {
         int tid = tid0;
         asm volatile("" : "+v"(tid));   // (per-job opaque copy, as in gpcc_chain_role)
         if (tid == 0) {
             int j = -1;
-            const int qd = a.quarters ? 4 : 1;
-            while (ks < c.nt) {
-                const int n = c.nt - ks - 1, np = n + 1;   // np: rows below the diagonal tile of step ks - 1
-                const int nsol = n >= 1 ? 4 * (n - (a.helpers ? 1 : 0)) : 0;   // (with helpers the solves of tile (k+1,k) are not queue jobs)
-                const int urgent = n >= 2 ? nsol + qd * n + (2 * n - 4) : nsol;
-                const int far = (ks >= 1 && np >= 5) ? (np - 4) * (np - 3) / 2 : 0;
-                const int near = n >= 4 ? n - 3 : 0;
-                const int nj = g.cnt * (urgent + far + near);
+            while (ks < c.nt) {   // (the job order: gpcc_chain_queue.h)
+                const int nj = g.cnt * gpcc_chain_list_len(c.nt, ks, a.helpers, a.quarters);
                 const int t = (nj > 0) ? (int)gpcc_flag_add(&a.words[16 + ks], 1u) : 0;
                 if (t < nj) {
                     j = t;
@@ -1098,37 +1087,8 @@ __global__ __launch_bounds__(GPCC_CHAIN_THREADS, 2) void gpcc_chain_kernel(GpccC
             }
             int kind = -1, jk = 0, jI = 0, jJ = 0, jq = 0;
             if (j >= 0) {
-                const int n = c.nt - ks - 1, np = n + 1;
-                const int nsol = n >= 1 ? 4 * (n - (a.helpers ? 1 : 0)) : 0;
-                const int nnext = n >= 2 ? qd * n : 0;
-                const int urgent = n >= 2 ? nsol + nnext + (2 * n - 4) : nsol;
-                const int far = (ks >= 1 && np >= 5) ? (np - 4) * (np - 3) / 2 : 0;
-                int jj = j / g.cnt, ra, rb;
-                if (jj < nsol) {                  // quarter solve (I, ks, q)
-                    kind = 1; jk = ks; jI = ks + 1 + (a.helpers ? 1 : 0) + jj / 4; jq = jj % 4;
-                } else if (jj < nsol + nnext) {   // what the next step needs at once: local column 0, (k+2.., k+1), then the diagonal tile (k+2,k+2) -- in quarters for small groups
-                    const int u = (jj - nsol) / qd;
-                    kind = a.quarters ? 3 : 2; jk = ks; jq = (jj - nsol) % qd;
-                    jI = (u < n - 1) ? ks + 2 + u : ks + 2;
-                    jJ = (u < n - 1) ? ks + 1 : ks + 2;
-                } else if (jj < urgent) {         // next to the diagonal: (k+3,k+2), (k+3,k+3), (k+4,k+3), ...
-                    const int bnd = jj - nsol - nnext + 2;
-                    ra = 1 + bnd / 2;
-                    rb = (bnd & 1) ? ra : ra - 1;
-                    kind = 2; jk = ks; jI = ks + 1 + ra; jJ = ks + 1 + rb;
-                } else if (jj < urgent + far) {   // the bulk of step ks - 1: local columns rb = 2 .. np - 3, rows ra = rb + 2 .. np - 1
-                    int u = jj - urgent;
-                    rb = 2;
-                    while (u >= np - 2 - rb) {
-                        u -= np - 2 - rb;
-                        ++rb;
-                    }
-                    ra = rb + 2 + u;
-                    kind = 2; jk = ks - 1; jI = ks + ra; jJ = ks + rb;
-                } else {                          // the rest of local column 1 of this step: (k+4.., k+2)
-                    ra = 3 + (jj - urgent - far);
-                    kind = 2; jk = ks; jI = ks + 1 + ra; jJ = ks + 2;
-                }
+                const GpccChainJob jb = gpcc_chain_decode(c.nt, ks, j / g.cnt, a.helpers, a.quarters);
+                kind = jb.kind; jk = jb.k; jI = jb.I; jJ = jb.J; jq = jb.q;
             }
             if (kind == 1) jJ = jq;   // (a solve's quarter travels in the column slot)
             ctl[16] = jq;

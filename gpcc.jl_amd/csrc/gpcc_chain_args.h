@@ -2,6 +2,7 @@
 // persistent few-evaluation launch share: sizes, the argument block, the launcher.
 #pragma once
 #include "gpcc_kernels.hip.h"
+#include "gpcc_chain_queue.h"
 
 
 #define GPCC_CHAIN_MAX_EVALS 16
