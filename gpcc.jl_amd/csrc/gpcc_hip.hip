@@ -126,6 +126,9 @@ struct gpcc_handle_s {
     long chain_work_max = 4096; // option "chain_work_max": ... and at most this many evaluations x tile-steps^2 (12 at N <= 2048, 4 at N = 4096: above, the
                                 // launch-per-step path is the faster one -- profiles/r05/latency_small_batches.log)
     int chain_quarters_max = 2; // option "chain_quarters_max": groups of at most this many evaluations update the tiles the next step needs at once in quarter-tile jobs
+    int chain_workers_max = 0;  // option "chain_workers_max": at most this many worker workgroups per persistent launch (0 = as many as the widest step has jobs, up to the
+                                // chip): caller PROCESSES that share a GPU at N >= 2048 (each launch would otherwise ask for every CU and the launches queue)
+    long chain_last_grid = 0;   // workgroups of the last persistent launch ("chain_last_grid")
     int chain_helpers_max = 6; // option "chain_helpers_max": groups of at most this many evaluations give each evaluation four more dedicated workgroups
                                // (the quarter solves of the tile below the diagonal run beside every diagonal step instead of being queue jobs)
     int chain_trace = 0;       // option "chain_trace": the chain workgroups stamp their phases (gpcc_chain_trace; tools/chain_trace.py)
@@ -201,6 +204,8 @@ struct gpcc_handle_s {
     // K_ii / d_i over its pivots; where the error model built on them exceeds the budget, the evaluation is repeated
     // on an internal fp64 handle (`fb`, created on first use) and its result replaces the fp32 one.
     int fp32_guard = 1;              // option "fp32_guard": 0 = raw fp32 results
+    int fp32_chain = 1;              // option "fp32_chain": a call the persistent launch would take on an fp64 handle is evaluated by the fp64 twin
+    long fp32_chain_count = 0;       // evaluations that went that way ("fp32_chain_count")
     long cond_cap = 0, fb_cap = 0;
     int *d_fb_idx = nullptr, *d_fb_info = nullptr;
     double *d_fb_par = nullptr, *d_fb_out = nullptr;
@@ -498,6 +503,9 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
     } else if (!strcmp(key, "chain_work_max")) {
         if (v < 0) return fail(h, GPCC_ERR_ARGUMENT, "chain_work_max must be >= 0");
         h->chain_work_max = (long)v;
+    } else if (!strcmp(key, "chain_workers_max")) {
+        if (v < 0) return fail(h, GPCC_ERR_ARGUMENT, "chain_workers_max must be >= 0");
+        h->chain_workers_max = (int)v;
     } else if (!strcmp(key, "chain_quarters_max")) {
         if (v < 0 || v > GPCC_CHAIN_MAX_EVALS) return fail(h, GPCC_ERR_ARGUMENT, "chain_quarters_max must be in [0,%d]", GPCC_CHAIN_MAX_EVALS);
         h->chain_quarters_max = (int)v;
@@ -548,6 +556,8 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
         h->fit_threads = (int)v;
     } else if (!strcmp(key, "fp32_guard")) {
         h->fp32_guard = v != 0;
+    } else if (!strcmp(key, "fp32_chain")) {
+        h->fp32_chain = v != 0;
     } else if (!strcmp(key, "fp32_refine")) {
         h->fp32_refine = v != 0;
     } else if (!strcmp(key, "fp32_assemble")) {
@@ -580,6 +590,8 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "chain_helpers_max")) return h->chain_helpers_max;
     if (!strcmp(key, "chain_quarters_max")) return h->chain_quarters_max;
     if (!strcmp(key, "chain_work_max")) return h->chain_work_max;
+    if (!strcmp(key, "chain_workers_max")) return h->chain_workers_max;
+    if (!strcmp(key, "chain_last_grid")) return h->chain_last_grid;
     if (!strcmp(key, "shared_prefix")) return h->shared_prefix;
     if (!strcmp(key, "share_tiles")) return h->share_tiles;
     if (!strcmp(key, "N")) return h->N;
@@ -608,6 +620,8 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "small_n_active")) return (h->small_n && h->N <= GPCC_SMALLW_MAXN) ? 1 : 0;
     if (!strcmp(key, "small_n_count")) return h->small_count;
     if (!strcmp(key, "fp32_guard")) return h->fp32_guard;
+    if (!strcmp(key, "fp32_chain")) return h->fp32_chain;
+    if (!strcmp(key, "fp32_chain_count")) return h->fp32_chain_count;
     if (!strcmp(key, "fp32_refine")) return h->fp32_refine;
     if (!strcmp(key, "fp32_assemble")) return h->fp32_assemble;
     if (!strcmp(key, "fp32_guard_count")) return h->fb_count;
@@ -920,11 +934,13 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
         const int dedicated = (a.helpers ? 6 : 2) * g.cnt;                 // chain roles (+ the four solve helpers) per evaluation
         const int ncb = (a.helpers ? 48 : 16) * ((g.cnt + 7) / 8);         // their block range
         long workers = (long)g.cnt * gpcc_chain_jobs(c.nt - 1);   // the widest step; more workgroups than that would only spin
-        const long room = (long)h->n_cus - dedicated;
+        long room = (long)h->n_cus - dedicated;
+        if (h->chain_workers_max > 0 && room > h->chain_workers_max) room = h->chain_workers_max;
         if (workers > room) workers = room;
         if (workers < 1) workers = 1;
         const long grid = (dedicated + workers > ncb) ? dedicated + workers : ncb;   // (blocks of the dedicated range without a role work too)
         gpcc_chain_launch(c, g, a, (unsigned)grid, s);
+        h->chain_last_grid = grid;
         h->chain_count += g.cnt;
         return;
     }
@@ -1207,6 +1223,49 @@ __global__ void gpcc_scatter_results(int nf, const int *idx, const double *ll, c
     out_info[idx[i]] = info[i];
 }
 
+// the fp64 twin of an fp32 handle: the literal fp64 model on the same light curves, a small workspace of its own.  Behind the guard
+// (flagged evaluations are repeated by it) and behind "fp32_chain" (few-evaluation calls are evaluated by it in the first place).
+static int ensure_fb(gpcc_handle_t h, long want_slots)
+{
+    if (!h->fb) {
+        int rc = gpcc_create(&h->fb, h->L, h->Nl, h->t_host.data(), h->y_host.data(), h->sigma_host.data(), h->kernel_id, h->mb,
+                             GPCC_PRECISION_FP64, h->device);
+        if (rc) return fail(h, rc, "fp32 handle: creating the fp64 handle failed: %s", g_err.c_str());
+        gpcc_set_option(h->fb, "shared_prefix", 0);
+        gpcc_set_option(h->fb, "streams", 1);   // (its workspace is sized for one stream's slots)
+        h->fb_slots = 0;
+    }
+    if (want_slots > h->fb_slots) {   // it only ever grows
+        gpcc_set_option(h->fb, "slots_per_stream", want_slots);
+        h->fb_slots = want_slots;
+    }
+    return 0;
+}
+
+// fp32 handle, a call of a few evaluations (one objective(alpha, rho), marginaliseb.jl:133-141 as Optim calls it): on the
+// launch-per-step path such a group is bound by the latency of its serial chain, not by the matrix pipe -- fp32 tiles buy nothing
+// there -- and the persistent launch (gpcc_chain.hip.h) exists for fp64 tiles only.  The call is handed to the fp64 twin: its result
+// is the fp64 handle's, bit for bit (well inside the fp32 mode's 1e-3), in 2/3 of the time at N = 4096.  Same policy as takes_chain.
+static bool fp32_call_goes_to_fp64_chain(gpcc_handle_t h, int M)
+{
+    return h->precision == GPCC_PRECISION_FP32 && h->fp32_chain && !small_path(h) && !h->is_multi() && !h->prof && h->nt > 1 && h->chain_max > 0 &&
+           M <= h->chain_max && M <= GPCC_CHAIN_MAX_EVALS && M <= h->right_looking_max && (long)M * h->nt * h->nt <= h->chain_work_max;
+}
+
+static int fp32_prepare_fp64_chain(gpcc_handle_t h, int M)
+{
+    int rc = ensure_fb(h, 16);
+    if (rc) return rc;
+    h->fb->chain_max = h->chain_max;   // the twin follows this handle's few-evaluation options
+    h->fb->chain_work_max = h->chain_work_max;
+    h->fb->chain_helpers_max = h->chain_helpers_max;
+    h->fb->chain_quarters_max = h->chain_quarters_max;
+    h->fb->right_looking_max = h->right_looking_max;
+    h->cond_host.assign(2 * (size_t)M, 0.0);   // evaluated in fp64: nothing to guard
+    h->fp32_chain_count += M;
+    return 0;
+}
+
 static int fp32_guard_pass(gpcc_handle_t h, int M, const double *d_delays, const double *d_alpha, const double *d_rho,
                            double *d_loglik, int *d_info, hipStream_t caller)
 {
@@ -1228,17 +1287,11 @@ static int fp32_guard_pass(gpcc_handle_t h, int M, const double *d_delays, const
             h->fb_idx_host.push_back(i);
     const int nf = (int)h->fb_idx_host.size();
     if (nf == 0) return 0;
-    if (!h->fb) {   // the literal fp64 model on the same light curves, a small workspace of its own
-        int rc = gpcc_create(&h->fb, h->L, h->Nl, h->t_host.data(), h->y_host.data(), h->sigma_host.data(), h->kernel_id, h->mb,
-                             GPCC_PRECISION_FP64, h->device);
-        if (rc) return fail(h, rc, "fp32 guard: creating the fp64 handle failed: %s", g_err.c_str());
-        gpcc_set_option(h->fb, "shared_prefix", 0);
-        gpcc_set_option(h->fb, "streams", 1);   // (its workspace is sized below for one stream's slots)
-        h->fb_slots = 0;
-    }
     {   // workspace of the fp64 repeat: as many slots as evaluations to repeat (a batch that is mostly ill-conditioned then
         // runs as few large groups on the fused path instead of many 16-wide right-looking ones), between 16 and 128,
         // within a quarter of the memory that is free right now; it only ever grows
+        int rc0 = ensure_fb(h, 0);
+        if (rc0) return rc0;
         size_t free_b = 0, total_b = 0;
         long want = nf < 16 ? 16 : (nf > 128 ? 128 : nf);
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -1247,10 +1300,8 @@ static int fp32_guard_pass(gpcc_handle_t h, int M, const double *d_delays, const
             if (want > fit) want = fit;
         }
         if (want < 1) want = 1;
-        if (want > h->fb_slots) {
-            gpcc_set_option(h->fb, "slots_per_stream", want);
-            h->fb_slots = want;
-        }
+        rc0 = ensure_fb(h, want);
+        if (rc0) return rc0;
     }
     if (nf > h->fb_cap) {
         hipFree(h->d_fb_idx); hipFree(h->d_fb_par); hipFree(h->d_fb_out); hipFree(h->d_fb_info);
@@ -1287,6 +1338,13 @@ extern "C" int gpcc_loglik_batch_device(gpcc_handle_t h, int M, const double *d_
     int rc = stream_on_device(h, stream, h->device);
     if (rc) return rc;
     hipStream_t caller = (hipStream_t)stream;
+    if (fp32_call_goes_to_fp64_chain(h, M)) {
+        rc = fp32_prepare_fp64_chain(h, M);
+        if (rc) return rc;
+        rc = gpcc_loglik_batch_device(h->fb, M, d_delays, d_alpha, d_rho, d_loglik, d_info, stream);
+        if (rc) return fail(h, rc, "fp32 handle, few-evaluation call in fp64: %s", h->fb->err.c_str());
+        return 0;
+    }
     const bool small = small_path(h);
     if (small && h->precision == GPCC_PRECISION_FP32) h->cond_host.assign(2 * (size_t)M, 0.0);   // evaluated in fp64: nothing to guard
     const bool f32 = h->precision == GPCC_PRECISION_FP32 && !small;
@@ -1383,6 +1441,13 @@ extern "C" int gpcc_loglik_batch(gpcc_handle_t h, int M, const double *delays, c
         HIPCHK(h, hipStreamSynchronize(ln.stream));
         memcpy(loglik, ln.ll, sizeof(double) * M);
         memcpy(info, ln.info, sizeof(int) * M);
+        return 0;
+    }
+    if (fp32_call_goes_to_fp64_chain(h, M)) {
+        int rc = fp32_prepare_fp64_chain(h, M);
+        if (rc) return rc;
+        rc = gpcc_loglik_batch(h->fb, M, delays, alpha, rho, loglik, info);
+        if (rc) return fail(h, rc, "fp32 handle, few-evaluation call in fp64: %s", h->fb->err.c_str());
         return 0;
     }
     if (h->precision == GPCC_PRECISION_FP64 && h->chain_max > 0 && M <= h->chain_max && M <= h->right_looking_max && M <= GPCC_CHAIN_MAX_EVALS &&

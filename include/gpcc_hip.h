@@ -106,6 +106,10 @@ int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms
  *                                     0 = the two-launches-per-step path below
  *   chain_work_max           4096     ... and evaluations x (N/128)^2 at most this (12 evaluations up to N = 2048, 4 at N = 4096: above,
  *                                     the path below is faster)
+ *   chain_workers_max        0        ... at most this many worker workgroups per launch (0 = as many as the widest step has jobs, up to the
+ *                                     chip).  For P caller processes sharing a GPU at N >= 2048, where every launch would ask for all CUs and
+ *                                     the launches queue: about n_cus / P - 6 (4 processes at N = 4096: 1210 instead of 800 evaluations/s in
+ *                                     total; a single caller is 2.4x slower with it).  Changes no result.
  *   chain_helpers_max        6        ... with four more dedicated workgroups per evaluation (the solves of the tile below the diagonal run
  *                                     beside every diagonal step) for groups of at most this many evaluations
  *   chain_quarters_max       2        ... and the tile updates the next step needs at once as four quarter-tile jobs each, for groups of
@@ -137,10 +141,14 @@ int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms
  *   fp32_refine              1        fp32 handles: fp64 refinement of the quadratic forms
  *   fp32_guard               1        fp32 handles: evaluations whose pivot ratios exceed the limits are repeated in fp64
  *   fp32_assemble            1        fp32 handles: tiles inside one band pair are evaluated in fp32
+ *   fp32_chain               1        fp32 handles: a call that chain_max / chain_work_max would give to the persistent launch on an fp64
+ *                                     handle (one objective(alpha, rho) at N >= 384: bound by latency, not by the matrix pipe) is
+ *                                     evaluated in fp64 by it, on the handle's internal fp64 twin: the fp64 handle's bits, conditioning
+ *                                     estimates 0; 0 = fp32 tiles on the launch-per-step path ("fp32_chain_count": evaluations so far)
  *
  * Read-only keys of gpcc_get_option: "N", "Np", "precision", "bytes_per_slot", "share_tiles", "n_devices", "gather_mode",
  * "gather_width", "small_n_max" (383), "small_n_active", "small_n_count", "chain_count" (evaluations that took the persistent
- * launch so far), "fp32_guard_count", "workspace_streams" / "workspace_slots" (what the workspace really holds: smaller than "streams" /
+ * launch so far), "chain_last_grid" (workgroups of the last one), "fp32_guard_count", "fp32_chain_count", "workspace_streams" / "workspace_slots" (what the workspace really holds: smaller than "streams" /
  * "slots_per_stream" only if the device's memory was short when it was allocated -- then gpcc_last_error carries a note; the
  * options themselves are never rewritten). */
 int gpcc_set_option(gpcc_handle_t handle, const char *key, long value);

@@ -10,6 +10,12 @@ using Random, Statistics, LinearAlgebra, Distributions, MiscUtil    # all alread
 
 const LIB = get(ENV, "GPCC_HIP_LIB", "libgpcc_hip.so")
 
+# Several Julia tasks / threads of ONE process, each with its own handle, each calling objective(α, ρ) (the pmap shape inside a process):
+# the HIP runtime spreads a process's streams over 4 hardware queues by default, so at most 4 launches run side by side.  8 queues:
+# 18 200 instead of 10 300 - 13 700 evaluations/s in total for 8 callers at N = 1024 (profiles/r05/concurrent_callers_round5b.log).
+# Must be in the environment before the first HIP call of the process, i.e. before the library is used.
+haskey(ENV, "GPU_MAX_HW_QUEUES") || (ENV["GPU_MAX_HW_QUEUES"] = "8")
+
 # kernel function identity -> id (src/util.jl:15-52); any other callable stays on the Julia path
 # (`include`d from src/GPCC.jl, this module's parent IS GPCC -- `Main.GPCC` would only exist after `using GPCC` in Main)
 const _G = parentmodule(@__MODULE__)

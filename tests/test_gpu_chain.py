@@ -122,15 +122,43 @@ def test_chain_status_codes(gp):
 
 
 def test_chain_is_fp64_only_and_other_paths_unchanged(gp, oracle):
-    """fp32 handles, groups above chain_max and the dense utilities keep their paths (chain_count stays 0) and their results."""
+    """The persistent launch works on fp64 tiles.  An fp32 handle hands a call that an fp64 handle's policy would give to it to its
+    fp64 twin (option fp32_chain, on): the fp64 handle's bits, nothing for the guard to do; with fp32_chain = 0 it keeps the fp32
+    launch-per-step path.  Groups above chain_max and the dense utilities keep their paths (chain_count unchanged) and their results."""
+    import torch
     from gpcc_amd import synthetic
     t, y, s, _ = synthetic.simulate_lightcurves([400, 400], seed=6)
     alpha, rho = synthetic.default_hyperparameters(y)
     d = np.stack([np.zeros(3), np.array([0.5, 1.5, 2.5])], 1)
-    ref, _ = oracle.loglik_batch("matern32", t, y, s, d, np.tile(alpha, (3, 1)), np.full(3, rho), True, nthreads=4)
+    A3, R3 = np.tile(alpha, (3, 1)), np.full(3, rho)
+    ref, _ = oracle.loglik_batch("matern32", t, y, s, d, A3, R3, True, nthreads=4)
+    with gp.Objective(t, y, s, "matern32") as obj:
+        ll64, _ = obj.loglik_batch(d, A3, R3)
+        assert obj.get_option("chain_count") == 3
     with gp.Objective(t, y, s, "matern32", precision="fp32") as obj:
-        ll, info = obj.loglik_batch(d, np.tile(alpha, (3, 1)), np.full(3, rho))
-        assert obj.get_option("chain_count") == 0 and (info == 0).all() and _rel(ll, ref) <= 1e-3
+        ll, info = obj.loglik_batch(d, A3, R3)
+        assert obj.get_option("chain_count") == 0 and obj.get_option("fp32_chain_count") == 3 and (info == 0).all()
+        assert np.array_equal(ll, ll64) and _rel(ll, ref) <= 1e-8
+        assert np.array_equal(obj.conditioning(3), np.zeros((3, 2))) and obj.get_option("fp32_guard_count") == 0
+        dev = torch.device("cuda", 0)   # the device-pointer entry goes the same way
+        out = torch.empty(3, dtype=torch.float64, device=dev)
+        oinfo = torch.empty(3, dtype=torch.int32, device=dev)
+        obj.loglik_batch_device(torch.as_tensor(d, device=dev), torch.as_tensor(A3, device=dev), torch.as_tensor(R3, device=dev), out=out, info=oinfo)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), ll64) and obj.get_option("fp32_chain_count") == 6
+        bad = A3.copy()
+        bad[1, 0] = -1.0   # an argument error beside valid evaluations comes back as the fp64 handle reports it
+        llb, infob = obj.loglik_batch(d, bad, R3)
+        assert infob[1] == -1 and np.isnan(llb[1]) and infob[0] == 0 and infob[2] == 0 and llb[0] == ll64[0]
+        M = 13              # above chain_max: fp32 tiles as before
+        dd = np.stack([np.zeros(M), np.linspace(0, 6, M)], 1)
+        before = obj.get_option("fp32_chain_count")
+        ll13, info13 = obj.loglik_batch(dd, np.tile(alpha, (M, 1)), np.full(M, rho))
+        assert obj.get_option("fp32_chain_count") == before and (info13 == 0).all()
+        obj.set_option("fp32_chain", 0)
+        ll32, info32 = obj.loglik_batch(d, A3, R3)
+        assert obj.get_option("fp32_chain_count") == before and (info32 == 0).all() and _rel(ll32, ref) <= 1e-3
+        assert not np.array_equal(ll32, ll64)
     with gp.Objective(t, y, s, "matern32", slots_per_stream=32) as obj:
         M = 13
         dd = np.stack([np.zeros(M), np.linspace(0, 6, M)], 1)
@@ -224,3 +252,30 @@ def test_chain_device_pointer_entry_and_concurrent_handles(gp):
         x.join()
     for r in results:
         assert r is not None and all(v == ref for v in r)
+
+
+def test_chain_worker_count_changes_no_bit(gp):
+    """The size of the persistent launch is a scheduling matter: chain_workers_max (what caller processes sharing a GPU set) changes
+    the grid, never a result -- a tile's sums do not depend on which workgroup forms them, and any number of workers >= 1 drains the
+    queue."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([700, 600], seed=10)   # 11 tile steps
+    alpha, rho = synthetic.default_hyperparameters(y)
+    M = 2
+    dd = np.stack([np.zeros(M), np.array([0.7, 2.9])], 1)
+    aa, rr = np.tile(alpha, (M, 1)), np.full(M, rho)
+    with gp.Objective(t, y, s, "matern52", slots_per_stream=16, streams=1) as obj:
+        assert obj.get_option("chain_workers_max") == 0
+        ll, info = obj.loglik_batch(dd, aa, rr)
+        full = obj.get_option("chain_last_grid")
+        assert (info == 0).all() and full > 100
+        for cap in (1, 7, 40):
+            obj.set_option("chain_workers_max", cap)
+            ll_c, info_c = obj.loglik_batch(dd, aa, rr)
+            grid = obj.get_option("chain_last_grid")
+            assert np.array_equal(ll_c, ll) and (info_c == 0).all() and grid < full and grid <= max(12 + cap, 48), (cap, grid)
+        obj.set_option("chain_workers_max", 0)
+        ll_c, _ = obj.loglik_batch(dd, aa, rr)
+        assert np.array_equal(ll_c, ll) and obj.get_option("chain_last_grid") == full
+        with pytest.raises(Exception):
+            obj.set_option("chain_workers_max", -1)

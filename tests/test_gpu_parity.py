@@ -568,6 +568,7 @@ def test_fp32_medium_vs_oracle(gp, oracle, kname, mb):
     assert ok.sum() >= M // 2
     res = {}
     with gp.Objective(t, y, s, kname, marginalise_b=mb, precision="fp32") as obj:
+        obj.set_option("fp32_chain", 0)   # the fp32 tile kernels are what this test is about (a group of 12 would go to the fp64 twin)
         for mode in (0, 1):   # elements of the fp32 tiles evaluated in fp64 and rounded once / evaluated in fp32 (option "fp32_assemble")
             obj.set_option("fp32_assemble", mode)
             ll, info = obj.loglik_batch(delays, alphas, rhos)
@@ -950,6 +951,8 @@ def test_handle_lifetimes_leave_no_device_memory_behind(gp):
     free0 = None
     for it in range(24):
         with gp.Objective(t, y, s, "matern32", precision="fp32" if it % 2 else "fp64", slots_per_stream=16) as obj:
+            if it % 4 == 1:
+                obj.set_option("fp32_chain", 0)   # fp32 tiles for the few-evaluation calls too (it % 4 == 3: they go to the fp64 twin and its persistent launch)
             obj.loglik_batch(d, np.tile(alpha, (M, 1)), np.full(M, rho))
             obj.loglik_batch(d[:3], np.tile(alpha, (3, 1)), np.full(3, rho))      # small group: spread map
             if it % 4 == 0:
@@ -961,6 +964,8 @@ def test_handle_lifetimes_leave_no_device_memory_behind(gp):
                 obj.loglik_batch(d[:2], np.tile(alpha * 60.0, (2, 1)), np.full(2, rho))
                 if it % 4 == 1:
                     assert obj.get_option("fp32_guard_count") > 0
+                else:
+                    assert obj.get_option("fp32_chain_count") >= 2 and obj.get_option("fp32_guard_count") == 0
         if it % 6 == 0:
             with gp.Objective(t, y, s, "matern32", devices=[0, 0]) as multi:          # a multi-device handle: sub-handles, gather buffers
                 multi.loglik_batch(d, np.tile(alpha, (M, 1)), np.full(M, rho))

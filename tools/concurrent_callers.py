@@ -36,10 +36,16 @@ def caller(obj, alpha, rho, seconds, start_evt, out, idx):
     out[idx] = lat
 
 
+OPTS = []   # (key, value) applied to every handle (--opt key=value)
+
+
 def run_threads(nb, P, seconds):
     import gpcc_amd
     t, y, s, alpha, rho = make_problem(nb)
     objs = [gpcc_amd.Objective(t, y, s, "matern32", slots_per_stream=16, streams=1) for _ in range(P)]
+    for o in objs:
+        for k, v in OPTS:
+            o.set_option(k, v)
     out = [None] * P
     evt = threading.Event()
     th = [threading.Thread(target=caller, args=(objs[i], alpha, rho, seconds, evt, out, i)) for i in range(P)]
@@ -57,13 +63,15 @@ def run_threads(nb, P, seconds):
     return len(lat) / wall, np.median(lat) * 1e3, np.percentile(lat, 95) * 1e3
 
 
-def proc_main(nb, seconds, idx, barrier_file, q):
+def proc_main(nb, seconds, idx, barrier_file, q, opts=()):
     import torch
     torch.cuda.init()
     import gpcc_amd
     t, y, s, alpha, rho = make_problem(nb)
     d = np.array([0.0, 1.0 + 0.1 * idx])
     with gpcc_amd.Objective(t, y, s, "matern32", slots_per_stream=16, streams=1) as obj:
+        for k, v in opts:
+            obj.set_option(k, v)
         obj(alpha, rho, d)
         open("%s.%d" % (barrier_file, idx), "w").close()
         while not os.path.exists(barrier_file + ".go"):
@@ -83,7 +91,7 @@ def run_procs(nb, P, seconds):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     bf = os.path.join(tempfile.mkdtemp(prefix="gpcc_cc_"), "b")
-    ps = [ctx.Process(target=proc_main, args=(nb, seconds, i, bf, q)) for i in range(P)]
+    ps = [ctx.Process(target=proc_main, args=(nb, seconds, i, bf, q, tuple(OPTS))) for i in range(P)]
     for p in ps:
         p.start()
     while not all(os.path.exists("%s.%d" % (bf, i)) for i in range(P)):
@@ -106,11 +114,13 @@ def main():
     ap.add_argument("--threads", default="1,2,4,8,16")
     ap.add_argument("--procs", default="1,2,4")
     ap.add_argument("--seconds", type=float, default=2.0)
+    ap.add_argument("--opt", action="append", default=[], help="key=value set on every handle (e.g. chain_workers_max=58)")
     args = ap.parse_args()
+    OPTS.extend((kv.split("=")[0], int(kv.split("=")[1])) for kv in args.opt)
     import torch
     torch.cuda.init()
     import gpcc_amd
-    print("build:", gpcc_amd.build_info(), flush=True)
+    print("build:", gpcc_amd.build_info(), "| options:", dict(OPTS), "| GPU_MAX_HW_QUEUES =", os.environ.get("GPU_MAX_HW_QUEUES", "(default)"), flush=True)
     for nb in [int(v) for v in args.sizes.split(",")]:
         base = None
         for P in [int(v) for v in args.threads.split(",") if v]:

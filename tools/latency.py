@@ -18,6 +18,7 @@ ap.add_argument("--sizes", default="192,512,2048")      # per band; two bands
 ap.add_argument("--batches", default="1,2,4,8,12")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--bands", type=int, default=2)
+ap.add_argument("--precision", default="fp64", help="fp32: chain_max = 12 is then the fp64 twin's persistent launch (option fp32_chain), 0 the fp32 tiles per step")
 args = ap.parse_args()
 print("build:", gpcc_amd.build_info() if hasattr(gpcc_amd, "build_info") else "?")
 for Nb in [int(v) for v in args.sizes.split(",")]:
@@ -25,7 +26,7 @@ for Nb in [int(v) for v in args.sizes.split(",")]:
     alpha, rho = synthetic.default_hyperparameters(y)
     N = Nb * args.bands
     for cm in (0, 12):
-        with gpcc_amd.Objective(t, y, s, "matern32", slots_per_stream=64) as obj:
+        with gpcc_amd.Objective(t, y, s, "matern32", slots_per_stream=64, precision=args.precision) as obj:
             obj.set_option("chain_max", cm)
             obj.set_option("chain_work_max", 1 << 30)   # (every group up to chain_max: the default policy takes evaluations x (N/128)^2 <= 4096)
             for M in [int(v) for v in args.batches.split(",")]:
@@ -39,5 +40,5 @@ for Nb in [int(v) for v in args.sizes.split(",")]:
                     obj.loglik_batch(d, a, r)
                     ts.append(time.perf_counter() - t0)
                 med = np.median(ts)
-                print("N=%5d M=%2d %-28s: %7.3f ms per call (min %7.3f), %8.1f evals/s   loglik[0] %.12e" % (
-                    N, M, "persistent launch" if cm else "two launches per step", med * 1e3, min(ts) * 1e3, M / med, ll[0]), flush=True)
+                print("N=%5d M=%2d %s %-28s: %7.3f ms per call (min %7.3f), %8.1f evals/s   loglik[0] %.12e" % (
+                    N, M, args.precision, "persistent launch" if cm else "two launches per step", med * 1e3, min(ts) * 1e3, M / med, ll[0]), flush=True)
