@@ -50,9 +50,10 @@ with tempfile.TemporaryDirectory() as td:
                         cur = dict((kk, vv) for kk, vv in cur.items() if kk != "name") if "vgpr_count" not in cur else {}
                     cur["name"] = v
             else:
+                if k == "group_segment_fixed_size" and "name" in cur and "vgpr_count" in cur:
+                    rows.append(cur)   # (keys come in alphabetical order: this one is the FIRST of the next kernel's record, its name follows)
+                    cur = {}
                 cur[k] = int(v)
-                if k == "vgpr_spill_count" and "name" in cur:   # (the last key of a kernel's record in llvm-readelf's order)
-                    pass
         if "vgpr_count" in cur and "name" in cur:
             rows.append(cur)
 demangle = subprocess.run(["c++filt"], input="\n".join(r["name"] for r in rows), capture_output=True, text=True).stdout.splitlines()
