@@ -828,8 +828,12 @@ GPCC_CHAIN_FN bool gpcc_chain_trsmq(const GpccCtx &c, const GpccChainArgs &a, co
 // column tiles are complete (lcnt = 4 quarters) and the tile has received
 // column k - 1 (ver = k).
 // ------------------------------------------------------------------------------------------
-GPCC_CHAIN_FN bool gpcc_chain_upd(const GpccCtx &c, const GpccChainFlags &fl, const int slot, const int k, const int I, const int J, double *smem,
-                                  int *ctl, const int tid, unsigned long long *wt)
+// ncol > 1 (job kind 4, gpcc_chain_queue.h): the columns k .. k + ncol - 1 in one job -- the tiles of a tile row are contiguous, so
+// L(I,k) | L(I,k+1) | ... and L(J,k) | L(J,k+1) | ... are simply operands of 8 ncol chunks instead of 8; the same sums in the same order as
+// ncol jobs in a row (what a job stores and the next one loads are the same doubles), one fixed cost (polls, first copies, the tile in and
+// out: ~6 us) instead of ncol.
+GPCC_CHAIN_FN bool gpcc_chain_upd(const GpccCtx &c, const GpccChainFlags &fl, const int slot, const int k, const int I, const int J, const int ncol,
+                                  double *smem, int *ctl, const int tid, unsigned long long *wt)
 {
     typedef GpccPrec<double> P;
     constexpr int CH = 2048;
@@ -837,9 +841,10 @@ GPCC_CHAIN_FN bool gpcc_chain_upd(const GpccCtx &c, const GpccChainFlags &fl, co
     const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, q = lane >> 4, sw = gpcc_sw(lr);
     if (tid < 64) {   // the three inputs are polled by three lanes side by side (one after the other: three round trips of 0.6 us when all are there already)
         bool ok = true;
-        if (tid < 3) {
-            const unsigned *p = (tid == 0) ? &fl.lcnt[gpcc_tile_idx(I, k)] : (tid == 1) ? &fl.lcnt[gpcc_tile_idx(J, k)] : &fl.ver[gpcc_tile_idx(I, J)];
-            ok = gpcc_wait_ge(p, (tid == 2) ? 4u * (unsigned)k : 4u, fl.abortw, 0x400u + (unsigned)tid);
+        if (tid < 2 * ncol + 1) {   // lane 0: the tile has received column k - 1; lanes 1 .. 2 ncol: the column tiles of rows I and J are solved
+            const int cc = k + ((tid - 1) >> 1);
+            const unsigned *p = (tid == 0) ? &fl.ver[gpcc_tile_idx(I, J)] : &fl.lcnt[gpcc_tile_idx((tid & 1) ? I : J, cc)];
+            ok = gpcc_wait_ge(p, (tid == 0) ? 4u * (unsigned)k : 4u, fl.abortw, 0x400u + (unsigned)(tid > 2 ? 2 : tid));
         }
         const bool all = __all(ok);
         if (tid == 0) {
@@ -873,16 +878,19 @@ GPCC_CHAIN_FN bool gpcc_chain_upd(const GpccCtx &c, const GpccChainFlags &fl, co
     const double *pa1 = smem + (wr * 32 + lr) * 16 + (((2 * q + 1) ^ sw) * 2);
     const double *pb0 = smem + CH + (wc * 64 + lr) * 16 + (((2 * q) ^ sw) * 2);
     const double *pb1 = smem + CH + (wc * 64 + lr) * 16 + (((2 * q + 1) ^ sw) * 2);
+    for (int cb = 0; cb < ncol; ++cb) {   // ncol tiles of K: the chunks of L(I,k) and L(J,k) and, contiguous behind them, of the columns that follow
+      const bool lastcol = (cb == ncol - 1);
 #pragma unroll
-    for (int ch = 0; ch < 8; ++ch) {   // one tile of K: the chunks of L(I,k) and L(J,k)
+      for (int c8 = 0; c8 < 8; ++c8) {
+        const int ch = cb * 8 + c8;
         // chunk ch has landed (4 DMA instructions per wave and chunk; chunk ch + 1 may still fly); behind the barrier every wave has
         // finished chunk ch - 1, whose stage takes chunk ch + 2
-        if (ch < 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (ch < 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (c8 < 6 || !lastcol) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (c8 == 6) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (ch + 3 < 8) gpcc_dma_chunk_sc1(gA + (long)(ch + 3) * CH, gB + (long)(ch + 3) * CH, smem_addr + ((ch + 3) % 4) * 2 * GPCC_CHUNK_BYTES, wave, lane);
-        const int so = (ch % 4) * 2 * CH;
+        if (c8 < 5 || !lastcol) gpcc_dma_chunk_sc1(gA + (long)(ch + 3) * CH, gB + (long)(ch + 3) * CH, smem_addr + ((c8 + 3) % 4) * 2 * GPCC_CHUNK_BYTES, wave, lane);
+        const int so = (c8 % 4) * 2 * CH;
         d2 a2[2][2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
@@ -904,6 +912,7 @@ GPCC_CHAIN_FN bool gpcc_chain_upd(const GpccCtx &c, const GpccChainFlags &fl, co
 #pragma unroll
                     for (int f = 0; f < 2; ++f) acc[fm][2 * h + f] = P::mfma(a2[fm][s2 / 2][s2 % 2], b[f][s2 / 2][s2 % 2], acc[fm][2 * h + f]);
         }
+      }
     }
     // out straight from the registers as 16-byte sc1 stores: a lane pair (columns lr, lr ^ 1) swaps half of its rows, after which the even
     // lane holds columns (lr, lr + 1) of rows q, q + 4 and the odd lane those of rows q + 8, q + 12 -- one store instruction then
@@ -929,7 +938,7 @@ GPCC_CHAIN_FN bool gpcc_chain_upd(const GpccCtx &c, const GpccChainFlags &fl, co
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) gpcc_flag_st(&fl.ver[gpcc_tile_idx(I, J)], 4u * (unsigned)(k + 1));
+    if (tid == 0) gpcc_flag_st(&fl.ver[gpcc_tile_idx(I, J)], 4u * (unsigned)(k + ncol));
     return true;
 }
 
@@ -1077,7 +1086,7 @@ __global__ __launch_bounds__(GPCC_CHAIN_THREADS, 2) void gpcc_chain_kernel(GpccC
         if (tid == 0) {
             int j = -1;
             while (ks < c.nt) {   // (the job order: gpcc_chain_queue.h)
-                const int nj = g.cnt * gpcc_chain_list_len(c.nt, ks, a.helpers, a.quarters);
+                const int nj = g.cnt * gpcc_chain_list_len(c.nt, ks, a.helpers, a.quarters, a.batch);
                 const int t = (nj > 0) ? (int)gpcc_flag_add(&a.words[16 + ks], 1u) : 0;
                 if (t < nj) {
                     j = t;
@@ -1087,7 +1096,7 @@ __global__ __launch_bounds__(GPCC_CHAIN_THREADS, 2) void gpcc_chain_kernel(GpccC
             }
             int kind = -1, jk = 0, jI = 0, jJ = 0, jq = 0;
             if (j >= 0) {
-                const GpccChainJob jb = gpcc_chain_decode(c.nt, ks, j / g.cnt, a.helpers, a.quarters);
+                const GpccChainJob jb = gpcc_chain_decode(c.nt, ks, j / g.cnt, a.helpers, a.quarters, a.batch);
                 kind = jb.kind; jk = jb.k; jI = jb.I; jJ = jb.J; jq = jb.q;
             }
             if (kind == 1) jJ = jq;   // (a solve's quarter travels in the column slot)
@@ -1114,7 +1123,7 @@ __global__ __launch_bounds__(GPCC_CHAIN_THREADS, 2) void gpcc_chain_kernel(GpccC
         bool ok;
         if (kind == 1) ok = gpcc_chain_trsmq(c, a, fl, m, slot, k, jI, jJ, smem, ctl, tid, wt);
         else if (kind == 3) ok = gpcc_chain_updq(c, fl, slot, k, jI, jJ, jq, smem, ctl, tid, wt);
-        else ok = gpcc_chain_upd(c, fl, slot, k, jI, jJ, smem, ctl, tid, wt);
+        else ok = gpcc_chain_upd(c, fl, slot, k, jI, jJ, (kind == 4) ? jq : 1, smem, ctl, tid, wt);
         if (!ok) return;
         if (wt && tid == 0) wt[3] = wall_clock64();
         __syncthreads();

@@ -30,6 +30,7 @@ struct GpccChainArgs {
     int helpers;                 // 1: four more dedicated workgroups per evaluation run the quarter solves of the tile below the diagonal
                                  //    (few evaluations: latency); 0: those solves are queue jobs like the others (more workers)
     int quarters;                // 1: the updates the next step needs at once are queue jobs of a quarter tile (gpcc_chain_updq); 0: whole tiles
+    int batch;                   // 1, 2, 4 or 8: the widest column block of a bulk update job (job kind 4, gpcc_chain_queue.h); 1: one column per job
 };
 
 // per-evaluation jobs of step k (n = nt - k - 1 tile rows below the diagonal tile): 4 n quarter solves + n(n+1)/2 - 1 tile updates (tile

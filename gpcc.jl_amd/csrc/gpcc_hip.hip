@@ -129,6 +129,9 @@ struct gpcc_handle_s {
     int chain_workers_max = 0;  // option "chain_workers_max": at most this many worker workgroups per persistent launch (0 = as many as the widest step has jobs, up to the
                                 // chip): caller PROCESSES that share a GPU at N >= 2048 (each launch would otherwise ask for every CU and the launches queue)
     long chain_last_grid = 0;   // workgroups of the last persistent launch ("chain_last_grid")
+    int chain_batch = 8;        // option "chain_batch": bulk tile updates of the persistent launch take aligned blocks of up to this many columns per job (1, 2, 4, 8)
+                                // where the tile has the slack
+    long chain_batch_min = 40000; // option "chain_batch_min": ... for groups with evaluations x (N/128)^3 >= this (3 evaluations at N = 3072, 2 at N = 4096, 10 at N = 2048)
     int chain_helpers_max = 6; // option "chain_helpers_max": groups of at most this many evaluations give each evaluation four more dedicated workgroups
                                // (the quarter solves of the tile below the diagonal run beside every diagonal step instead of being queue jobs)
     int chain_trace = 0;       // option "chain_trace": the chain workgroups stamp their phases (gpcc_chain_trace; tools/chain_trace.py)
@@ -506,6 +509,12 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
     } else if (!strcmp(key, "chain_workers_max")) {
         if (v < 0) return fail(h, GPCC_ERR_ARGUMENT, "chain_workers_max must be >= 0");
         h->chain_workers_max = (int)v;
+    } else if (!strcmp(key, "chain_batch")) {
+        if (v != 1 && v != 2 && v != 4 && v != GPCC_CHAIN_MAX_BATCH) return fail(h, GPCC_ERR_ARGUMENT, "chain_batch must be 1, 2, 4 or %d", GPCC_CHAIN_MAX_BATCH);
+        h->chain_batch = (int)v;
+    } else if (!strcmp(key, "chain_batch_min")) {
+        if (v < 0) return fail(h, GPCC_ERR_ARGUMENT, "chain_batch_min must be >= 0");
+        h->chain_batch_min = (long)v;
     } else if (!strcmp(key, "chain_quarters_max")) {
         if (v < 0 || v > GPCC_CHAIN_MAX_EVALS) return fail(h, GPCC_ERR_ARGUMENT, "chain_quarters_max must be in [0,%d]", GPCC_CHAIN_MAX_EVALS);
         h->chain_quarters_max = (int)v;
@@ -591,6 +600,8 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "chain_quarters_max")) return h->chain_quarters_max;
     if (!strcmp(key, "chain_work_max")) return h->chain_work_max;
     if (!strcmp(key, "chain_workers_max")) return h->chain_workers_max;
+    if (!strcmp(key, "chain_batch")) return h->chain_batch;
+    if (!strcmp(key, "chain_batch_min")) return h->chain_batch_min;
     if (!strcmp(key, "chain_last_grid")) return h->chain_last_grid;
     if (!strcmp(key, "shared_prefix")) return h->shared_prefix;
     if (!strcmp(key, "share_tiles")) return h->share_tiles;
@@ -732,6 +743,9 @@ static GpccChainArgs chain_args(gpcc_handle_t h, const GpccCtx &c, const GpccGro
     a.qbase = h->chain_qbase;
     a.helpers = (g.cnt <= h->chain_helpers_max) ? 1 : 0;
     a.quarters = (g.cnt <= h->chain_quarters_max) ? 1 : 0;
+    // (worker-bound launches only: a group whose chain is the bound gains nothing from longer jobs and loses a little balance --
+    //  profiles/r05/chain_batch_ab.log; the results are the same bits either way)
+    a.batch = ((long)g.cnt * c.nt * c.nt * c.nt >= h->chain_batch_min) ? h->chain_batch : 1;
     return a;
 }
 
@@ -1260,6 +1274,9 @@ static int fp32_prepare_fp64_chain(gpcc_handle_t h, int M)
     h->fb->chain_work_max = h->chain_work_max;
     h->fb->chain_helpers_max = h->chain_helpers_max;
     h->fb->chain_quarters_max = h->chain_quarters_max;
+    h->fb->chain_batch = h->chain_batch;
+    h->fb->chain_batch_min = h->chain_batch_min;
+    h->fb->chain_workers_max = h->chain_workers_max;
     h->fb->right_looking_max = h->right_looking_max;
     h->cond_host.assign(2 * (size_t)M, 0.0);   // evaluated in fp64: nothing to guard
     h->fp32_chain_count += M;

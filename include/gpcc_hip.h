@@ -110,6 +110,11 @@ int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms
  *                                     chip).  For P caller processes sharing a GPU at N >= 2048, where every launch would ask for all CUs and
  *                                     the launches queue: about n_cus / P - 6 (4 processes at N = 4096: 1210 instead of 800 evaluations/s in
  *                                     total; a single caller is 2.4x slower with it).  Changes no result.
+ *   chain_batch              8        ... bulk tile updates take aligned blocks of up to this many columns (1, 2, 4, 8) per job where a tile has
+ *                                     the slack -- far from the diagonal 8, towards it 4, 2, 1 (8 w chunks of K instead of 8: one fixed cost of
+ *                                     ~6 us per w x 13.7 us of MFMAs; the same sums in the same order -- the same bits); 1 = one column per job
+ *   chain_batch_min          40000    ... for groups of evaluations x (N/128)^3 >= this (the worker-bound ones: from 3 evaluations at N = 3072, 2 at
+ *                                     N = 4096; -3 ... -12 % there, nothing or slightly worse where the chain is the bound)
  *   chain_helpers_max        6        ... with four more dedicated workgroups per evaluation (the solves of the tile below the diagonal run
  *                                     beside every diagonal step) for groups of at most this many evaluations
  *   chain_quarters_max       2        ... and the tile updates the next step needs at once as four quarter-tile jobs each, for groups of

@@ -279,3 +279,34 @@ def test_chain_worker_count_changes_no_bit(gp):
         assert np.array_equal(ll_c, ll) and obj.get_option("chain_last_grid") == full
         with pytest.raises(Exception):
             obj.set_option("chain_workers_max", -1)
+
+
+def test_chain_column_blocks_change_no_bit(gp, oracle):
+    """Bulk update jobs of 1, 2, 4 or 8 columns (chain_batch; forced on at this size by chain_batch_min = 0): the same sums in the same order,
+    so the same bits -- single evaluations and a group, with and without the helper workgroups and quarter-tile jobs -- and the oracle's
+    value.  (The job order itself is checked for every size on the host: tests/abi/chain_queue_check.cpp.)"""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([1500, 1400], seed=12)   # 23 tile steps: blocks of 8 exist
+    alpha, rho = synthetic.default_hyperparameters(y)
+    M = 7
+    dd = np.stack([np.zeros(M), np.linspace(0.3, 5.0, M)], 1)
+    aa, rr = np.tile(alpha, (M, 1)) * np.linspace(0.8, 1.2, M)[:, None], np.full(M, rho)
+    ref, rinfo = oracle.loglik_batch("matern32", t, y, s, dd[:2], aa[:2], rr[:2], True, nthreads=2)
+    with gp.Objective(t, y, s, "matern32", slots_per_stream=16, streams=1) as obj:
+        assert obj.get_option("chain_batch") == 8
+        obj.set_option("chain_work_max", 1 << 30)
+        obj.set_option("chain_batch_min", 0)
+        out = {}
+        for w in (1, 2, 4, 8):
+            obj.set_option("chain_batch", w)
+            before = obj.get_option("chain_count")
+            one = np.array([obj(aa[i], rr[i], dd[i]) for i in range(2)])
+            grp, info = obj.loglik_batch(dd, aa, rr)
+            assert obj.get_option("chain_count") == before + 2 + M and (info == 0).all()
+            out[w] = (one, grp)
+        for w in (2, 4, 8):
+            assert np.array_equal(out[w][0], out[1][0]) and np.array_equal(out[w][1], out[1][1]), w
+        assert np.array_equal(out[8][0], out[8][1][:2])   # an evaluation does not depend on the group it travels in
+        assert (rinfo == 0).all() and _rel(out[8][0], ref) <= 1e-8
+        with pytest.raises(Exception):
+            obj.set_option("chain_batch", 3)
