@@ -19,6 +19,8 @@ ap.add_argument("--n-per-band", type=int, default=2048)
 ap.add_argument("--bands", type=int, default=2)
 ap.add_argument("--evals", type=int, default=1)
 ap.add_argument("--every", type=int, default=1, help="print every n-th step")
+ap.add_argument("--opt", action="append", default=[], help="key=value set on the handle (e.g. chain_batch=1)")
+ap.add_argument("--brief", action="store_true", help="only the sums and the workers' statistics")
 args = ap.parse_args()
 t, y, s, _ = synthetic.simulate_lightcurves([args.n_per_band] * args.bands, seed=1)
 alpha, rho = synthetic.default_hyperparameters(y)
@@ -27,6 +29,8 @@ d = np.concatenate([np.zeros((M, 1)), np.linspace(0, 20, M)[:, None] * np.ones((
 with gpcc_amd.Objective(t, y, s, "matern32", slots_per_stream=16) as obj:
     obj.set_option("chain_trace", 1)
     obj.set_option("chain_work_max", 1 << 30)   # (whatever the group size: the kernel itself is looked at)
+    for kv in args.opt:
+        obj.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     for _ in range(3):
         ll, info = obj.loglik_batch(d, np.tile(alpha, (M, 1)), np.full(M, rho))
     for m in range(M):
@@ -42,9 +46,12 @@ with gpcc_amd.Objective(t, y, s, "matern32", slots_per_stream=16) as obj:
             dg = tr[k, 2] - tr[k, 1]
             hand.append(h)
             diag.append(dg)
-            if k % args.every == 0 or k == nt - 1:
+            if (k % args.every == 0 or k == nt - 1) and not args.brief:
                 print("%4d %12.2f %12.2f %12.2f | %10.2f %10.2f %10.2f" % (k, tr[k, 0], tr[k, 1], tr[k, 2], h, dg, tr[k, 1] - tr[k, 0]))
         ks = nt // 2
+        if args.brief:
+            print("sum of hand-offs %.1f us, sum of diagonal steps %.1f us" % (sum(hand[1:]), sum(diag)))
+            continue
         b = tr[ks, 8:80].reshape(9, 8)
         print("block steps of diagonal step %d (us): wave 0 [fold | load block | 16 pivots | store] | wait at barrier 1 | inverse row + panel | total" % ks)
         for jb in range(9):
@@ -62,7 +69,7 @@ with gpcc_amd.Objective(t, y, s, "matern32", slots_per_stream=16) as obj:
     jt = obj.chain_jobs_trace()
     if len(jt):
         print("== workers: %d jobs stamped (whole group)" % len(jt))
-        for kind, name in ((1, "quarter-tile solve"), (2, "tile update"), (3, "quarter-tile update")):
+        for kind, name in ((1, "quarter-tile solve"), (2, "tile update"), (3, "quarter-tile update"), (4, "tile update, column block")):
             r = jt[jt[:, 0] == kind]
             if len(r):
                 wait, run = r[:, 4] - r[:, 3], r[:, 5] - r[:, 4]
@@ -71,7 +78,7 @@ with gpcc_amd.Objective(t, y, s, "matern32", slots_per_stream=16) as obj:
         span = jt[:, 5].max() - jt[:, 3].min()
         busy = (jt[:, 5] - jt[:, 4]).sum()
         print("   span %.1f us; sum of running time %.1f us = %.1f workgroups busy on average" % (span, busy, busy / span))
-        if M == 1:
+        if M == 1 and not args.brief:
             tr = obj.chain_trace(0)
             print("== what the chain of step k waited for (us, same clock): step k-1 published | last quarter solve of tile (k,k-1) claimed / inputs there / done |")
             print("   update of (k,k-1) by column k-2 done | update of (k,k) by column k-2 done | image of tile (k,k) complete")
