@@ -281,6 +281,22 @@ def test_chain_worker_count_changes_no_bit(gp):
             obj.set_option("chain_workers_max", -1)
 
 
+def test_fp32_multi_device_handle_hands_few_evaluations_to_the_fp64_twins(gp):
+    """A multi-device fp32 handle (two sub-handles on device 0) splits a call of four evaluations into two shares of two: each
+    sub-handle's fp64 twin evaluates its share with the persistent launch -- the fp64 handle's bits."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([330, 300], seed=14)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    M = 4
+    dd = np.stack([np.zeros(M), np.linspace(0.4, 3.1, M)], 1)
+    aa, rr = np.tile(alpha, (M, 1)), np.full(M, rho)
+    with gp.Objective(t, y, s, "OU") as obj:
+        ll64, info64 = obj.loglik_batch(dd, aa, rr)
+    with gp.Objective(t, y, s, "OU", precision="fp32", devices=[0, 0]) as multi:
+        ll, info = multi.loglik_batch(dd, aa, rr)
+    assert (info64 == 0).all() and (info == 0).all() and np.array_equal(ll, ll64)
+
+
 def test_chain_column_blocks_change_no_bit(gp, oracle):
     """Bulk update jobs of 1, 2, 4 or 8 columns (chain_batch; forced on at this size by chain_batch_min = 0): the same sums in the same order,
     so the same bits -- single evaluations and a group, with and without the helper workgroups and quarter-tile jobs -- and the oracle's
