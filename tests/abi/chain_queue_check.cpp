@@ -1,5 +1,5 @@
 // chain_queue_check.cpp -- host check of the job order of the persistent few-evaluation launch (gpcc.jl_amd/csrc/gpcc_chain_queue.h):
-// for every matrix size (nt = 2 .. 48 tile rows), with and without helper workgroups, with whole-tile and quarter-tile "next step"
+// for every matrix size (nt = 2 .. 64 tile rows: N <= 8192, all the default policy ever gives to the launch), with and without helper workgroups, with whole-tile and quarter-tile "next step"
 // updates, with bulk jobs of at most 1, 2, 4 and 8 columns:
 //   (1) coverage: every tile (I,k), I > k, is solved exactly once per quarter (by queue jobs, or -- tile (k+1,k) with helpers -- by the
 //       chain's helpers); every trailing tile (I,J), k < J <= I, except the chain's own (k+1,k+1), is updated by column k exactly
@@ -25,10 +25,15 @@ static int fails = 0;
         }                                        \
     } while (0)
 
+// nt = 64 is the largest matrix the default policy gives to the persistent launch (one evaluation x 64^2 = chain_work_max)
+#ifndef NT_MAX
+#define NT_MAX 64
+#endif
+
 int main()
 {
     long jobs_total = 0, pair_jobs = 0;
-    for (int nt = 2; nt <= 48; ++nt)
+    for (int nt = 2; nt <= NT_MAX; ++nt)
         for (int helpers = 0; helpers < 2; ++helpers)
             for (int quarters = 0; quarters < 2; ++quarters)
             for (int pairs = 1; pairs <= GPCC_CHAIN_MAX_BATCH; pairs *= 2) {   // (the widest column block of a bulk job)
@@ -129,6 +134,6 @@ int main()
                     }
                 }
             }
-    std::printf("chain queue: %ld jobs (%ld of several columns) over nt = 2 .. 48 x helpers x quarters x widest block 1, 2, 4, 8 checked, %d failures\n", jobs_total, pair_jobs, fails);
+    std::printf("chain queue: %ld jobs (%ld of several columns) over nt = 2 .. %d x helpers x quarters x widest block 1, 2, 4, 8 checked, %d failures\n", jobs_total, pair_jobs, NT_MAX, fails);
     return fails ? 1 : 0;
 }

@@ -77,18 +77,19 @@ def test_synthetic_recipe():
 
 def test_persistent_launch_job_order_covers_every_job_and_never_waits_forward(tmp_path):
     """The queue order of the persistent few-evaluation launch (csrc/gpcc_chain_queue.h, the same header the kernel compiles): for
-    nt = 2 .. 48, with and without helpers, whole-tile and quarter-tile updates -- every solve and every update exactly once, and every
-    input of a job produced earlier in the order or by the chain (whose own needs are earlier too): the oldest unfinished job can always
-    run, which is the launch's whole argument against deadlock."""
+    nt = 2 .. 64 (N <= 8192: all the default policy ever gives to the launch), with and without helpers, whole-tile and quarter-tile
+    updates, bulk jobs of at most 1, 2, 4, 8 columns -- every solve and every update exactly once, and every input of a job produced
+    earlier in the order or by the chain (whose own needs are earlier too): the oldest unfinished job can always run, which is the
+    launch's whole argument against deadlock.  Once under AddressSanitizer + UBSan (nt <= 32), once plain for the whole range."""
     import subprocess
-    exe = str(tmp_path / "chain_queue_check")
     src = os.path.join(ROOT, "tests", "abi", "chain_queue_check.cpp")
-    cc = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", src, "-o", exe],
-                        capture_output=True, text=True)
-    assert cc.returncode == 0, cc.stderr
-    run = subprocess.run([exe], capture_output=True, text=True, timeout=600)
-    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
-    assert "0 failures" in run.stdout
+    for tag, flags in (("san", ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-DNT_MAX=32"]), ("full", ["-O2"])):
+        exe = str(tmp_path / ("chain_queue_check_" + tag))
+        cc = subprocess.run(["g++", "-std=c++17"] + flags + [src, "-o", exe], capture_output=True, text=True)
+        assert cc.returncode == 0, cc.stderr
+        run = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+        assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+        assert "0 failures" in run.stdout and ("nt = 2 .. %d" % (32 if tag == "san" else 64)) in run.stdout
 
 
 def test_native_optimiser_under_sanitizers(tmp_path):
