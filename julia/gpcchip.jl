@@ -12,7 +12,7 @@ const LIB = get(ENV, "GPCC_HIP_LIB", "libgpcc_hip.so")
 
 # Several Julia tasks / threads of ONE process, each with its own handle, each calling objective(α, ρ) (the pmap shape inside a process):
 # the HIP runtime spreads a process's streams over 4 hardware queues by default, so at most 4 launches run side by side.  8 queues:
-# 18 200 instead of 10 300 - 13 700 evaluations/s in total for 8 callers at N = 1024 (profiles/r05/concurrent_callers_round5b.log).
+# 14 700 - 18 200 instead of 10 300 - 13 700 evaluations/s in total for 8 callers at N = 1024 (profiles/r05/concurrent_callers_round5b.log).
 # Must be in the environment before the first HIP call of the process, i.e. before the library is used.
 haskey(ENV, "GPU_MAX_HW_QUEUES") || (ENV["GPU_MAX_HW_QUEUES"] = "8")
 
