@@ -121,7 +121,9 @@ struct gpcc_handle_s {
                              // profiles/r03/two_streams_ab.log); a batch of one group is unaffected
     int slots_per_stream = 256, right_looking_max = GPCC_RIGHT_LOOKING_MAX;
     int fused_small_max = 12;  // groups of at most this many evaluations run gpcc_small_step (update + next diagonal step in one launch)
-    int chain_max = 12;        // option "chain_max": ... or, fp64 handles, as ONE persistent launch (gpcc_chain.hip.h); 0 = never
+    int chain_max = 16;        // option "chain_max": groups of at most this many evaluations run as ONE persistent launch (gpcc_chain.hip.h; fp64 handles, fp32 ones through their twin) where
+                               // the policy below says it wins; 0 = never
+    long chain_wide_work_max = 1024; // option "chain_wide_work_max": ... groups of 13 .. chain_max evaluations: evaluations x (N/128)^2 at most this (N <= 1024)
     std::atomic<long> chain_count{0};   // evaluations that took the persistent launch so far ("chain_count")
     long chain_work_max = 4096; // option "chain_work_max": ... and at most this many evaluations x tile-steps^2 (12 at N <= 2048, 4 at N = 4096: above, the
                                 // launch-per-step path is the faster one -- profiles/r05/latency_small_batches.log)
@@ -503,6 +505,9 @@ extern "C" int gpcc_set_option(gpcc_handle_t h, const char *key, long v)
     } else if (!strcmp(key, "chain_max")) {
         if (v < 0 || v > GPCC_CHAIN_MAX_EVALS) return fail(h, GPCC_ERR_ARGUMENT, "chain_max must be in [0,%d]", GPCC_CHAIN_MAX_EVALS);
         h->chain_max = (int)v;
+    } else if (!strcmp(key, "chain_wide_work_max")) {
+        if (v < 0) return fail(h, GPCC_ERR_ARGUMENT, "chain_wide_work_max must be >= 0");
+        h->chain_wide_work_max = (long)v;
     } else if (!strcmp(key, "chain_work_max")) {
         if (v < 0) return fail(h, GPCC_ERR_ARGUMENT, "chain_work_max must be >= 0");
         h->chain_work_max = (long)v;
@@ -599,6 +604,7 @@ extern "C" long gpcc_get_option(gpcc_handle_t h, const char *key)
     if (!strcmp(key, "chain_helpers_max")) return h->chain_helpers_max;
     if (!strcmp(key, "chain_quarters_max")) return h->chain_quarters_max;
     if (!strcmp(key, "chain_work_max")) return h->chain_work_max;
+    if (!strcmp(key, "chain_wide_work_max")) return h->chain_wide_work_max;
     if (!strcmp(key, "chain_workers_max")) return h->chain_workers_max;
     if (!strcmp(key, "chain_batch")) return h->chain_batch;
     if (!strcmp(key, "chain_batch_min")) return h->chain_batch_min;
@@ -719,11 +725,23 @@ static int ensure_chain(gpcc_handle_t h)
 }
 
 // a group of a few evaluations (one objective(alpha, rho)) on an fp64 handle's own workspace: the persistent launch
+// which group sizes the persistent launch wins at (profiles/r05/latency_small_batches.log, chain_13_to_16_evaluations_ab.log): up to 12
+// evaluations while evaluations x (N/128)^2 <= chain_work_max; 13 .. chain_max while <= chain_wide_work_max (N <= 1024: there the
+// alternative -- two halves on two streams -- is slower even when the halves overlap, and they only overlap when the runtime happens to
+// map the two streams onto different hardware queues: 0.45 against 0.52 / 0.89 ms for 13 evaluations at N = 1024)
+static bool chain_policy(gpcc_handle_t h, int cnt, int nt)
+{
+    if (h->chain_max <= 0 || cnt > h->chain_max || cnt > GPCC_CHAIN_MAX_EVALS || nt <= 1) return false;
+    // right_looking_max below its default switches the few-evaluation paths off for larger groups -- this one included (0: every group left-looking)
+    if (cnt > h->right_looking_max && h->right_looking_max < GPCC_RIGHT_LOOKING_MAX) return false;
+    return (long)cnt * nt * nt <= (cnt <= 12 ? h->chain_work_max : h->chain_wide_work_max);
+}
+
 static bool takes_chain(gpcc_handle_t h, const GpccCtx &c, int cnt, int concurrent = 1)
 {
     // (a half of a split group runs beside the other half on a second stream: the persistent launch has ONE set of flag words per
     //  workspace stream, and wants the chip to itself)
-    return concurrent <= 1 && h->chain_max > 0 && cnt <= h->chain_max && (long)cnt * c.nt * c.nt <= h->chain_work_max && cnt <= GPCC_CHAIN_MAX_EVALS && cnt <= h->right_looking_max && c.nt > 1 && c.nt_fact == c.nt &&
+    return concurrent <= 1 && chain_policy(h, cnt, c.nt) && c.nt_fact == c.nt &&
            !c.share_p && !c.store_l && c.nrhs == 1 && !c.woodbury && h->precision == GPCC_PRECISION_FP64 && c.tiles == (void *)h->d_tiles &&
            h->d_chain_words != nullptr && h->chain_streams == h->ws_streams;
 }
@@ -864,6 +882,7 @@ static int enqueue_factor(gpcc_handle_t h, const GpccCtx &c, const GpccGroup &g,
 // the group runs left-looking with the panel solve inside the update (gpcc_syrk_diag + gpcc_update_solve)
 static bool takes_fused_solve(gpcc_handle_t h, const GpccCtx &c, int cnt, int concurrent)
 {
+    if (takes_chain(h, c, cnt, concurrent)) return false;   // (one path per group: the persistent launch wants its tiles assembled)
     const bool right = (cnt <= h->right_looking_max) && (c.nt_fact == c.nt) && !c.share_p;
     // (the halves of a split group hide each other's serial diagonal-tile loop: the fused path pays from 64 evaluations per half on)
     const int min_cnt = (concurrent >= 2) ? h->fused_solve_min_split : h->fused_solve_min;
@@ -882,7 +901,7 @@ static int enqueue_group(gpcc_handle_t h, const GpccCtx &c_in, const GpccGroup &
     if (factor && !ext && h->fold_assembly && c.sep && c.nt > 1 && !c.share_p && c.nt_fact == c.nt && !c.store_l) {
         const bool right = g.cnt <= h->right_looking_max;
         if (takes_fused_solve(h, c, g.cnt, concurrent)) c.fold = 1;
-        else if (!(right && (g.cnt <= h->fused_small_max || takes_chain(h, c, g.cnt, concurrent)))) c.fold = 2;   // (not the few-evaluation paths)
+        else if (!((right && g.cnt <= h->fused_small_max) || takes_chain(h, c, g.cnt, concurrent))) c.fold = 2;   // (not the few-evaluation paths)
         // tile rows that straddle two bands or hold padding: the MIXED instantiations (a handle without such rows keeps the leaner ones)
         c.fold_mixed = (c.fold && (h->mixed_rows || c.kernel_id == 1)) ? 1 : 0;
     }
@@ -940,7 +959,7 @@ static void enqueue_factor_t(gpcc_handle_t h, const GpccCtx &c, const GpccGroup 
     // small groups (the single objective(alpha, rho) call): right-looking, many short jobs per step
     const bool right = (g.cnt <= h->right_looking_max) && (c.nt_fact == c.nt) && !c.share_p;
     const int p = c.share_p;   // shared prefix: steps k < p only involve the leader's rows < p and everyone's rows >= p
-    if (sizeof(T) == 8 && right && takes_chain(h, c, g.cnt, concurrent)) {
+    if (sizeof(T) == 8 && takes_chain(h, c, g.cnt, concurrent)) {
         // a few evaluations on an fp64 handle: ONE persistent launch -- two chain workgroups per evaluation, everybody else pulls jobs
         // (gpcc_chain.hip.h)
         ProfScope pr(h, GPCC_PROF_SMALL_STEP, s);
@@ -1110,7 +1129,7 @@ static int enqueue_batch(gpcc_handle_t h, int M, const double *d_delays, const d
     if (!h->share_now) h->share_now = (h->shared_prefix == 2);   // device pointers cannot be inspected: only on assertion
     if (h->chain_max > 0 && h->precision == GPCC_PRECISION_FP64 && h->nt > 1) {
         const int tail = (M % h->ws_slots) ? M % h->ws_slots : h->ws_slots;   // (only a batch's last group can be this small)
-        if (tail <= h->chain_max && tail <= h->right_looking_max) {
+        if (chain_policy(h, tail, h->nt)) {
             rc = ensure_chain(h);
             if (rc) return rc;
         }
@@ -1262,8 +1281,8 @@ static int ensure_fb(gpcc_handle_t h, long want_slots)
 // is the fp64 handle's, bit for bit (well inside the fp32 mode's 1e-3), in 2/3 of the time at N = 4096.  Same policy as takes_chain.
 static bool fp32_call_goes_to_fp64_chain(gpcc_handle_t h, int M)
 {
-    return h->precision == GPCC_PRECISION_FP32 && h->fp32_chain && !small_path(h) && !h->is_multi() && !h->prof && h->nt > 1 && h->chain_max > 0 &&
-           M <= h->chain_max && M <= GPCC_CHAIN_MAX_EVALS && M <= h->right_looking_max && (long)M * h->nt * h->nt <= h->chain_work_max;
+    return h->precision == GPCC_PRECISION_FP32 && h->fp32_chain && !small_path(h) && !h->is_multi() && !h->prof &&
+           chain_policy(h, M, h->nt);
 }
 
 static int fp32_prepare_fp64_chain(gpcc_handle_t h, int M)
@@ -1272,6 +1291,7 @@ static int fp32_prepare_fp64_chain(gpcc_handle_t h, int M)
     if (rc) return rc;
     h->fb->chain_max = h->chain_max;   // the twin follows this handle's few-evaluation options
     h->fb->chain_work_max = h->chain_work_max;
+    h->fb->chain_wide_work_max = h->chain_wide_work_max;
     h->fb->chain_helpers_max = h->chain_helpers_max;
     h->fb->chain_quarters_max = h->chain_quarters_max;
     h->fb->chain_batch = h->chain_batch;
@@ -1467,8 +1487,7 @@ extern "C" int gpcc_loglik_batch(gpcc_handle_t h, int M, const double *delays, c
         if (rc) return fail(h, rc, "fp32 handle, few-evaluation call in fp64: %s", h->fb->err.c_str());
         return 0;
     }
-    if (h->precision == GPCC_PRECISION_FP64 && h->chain_max > 0 && M <= h->chain_max && M <= h->right_looking_max && M <= GPCC_CHAIN_MAX_EVALS &&
-        h->nt > 1 && !h->prof) {
+    if (h->precision == GPCC_PRECISION_FP64 && chain_policy(h, M, h->nt) && !h->prof) {
         // One objective(alpha, rho) (marginaliseb.jl:133-141 as Optim calls it, :145-153): the whole call is pack -> two launches (assembly,
         // persistent factorisation) on workspace stream 0 -> one stream synchronisation.  Parameters are read from, results written to
         // pinned, device-mapped host memory by the kernels themselves: no copy calls, no events (the general path below costs ~50 us

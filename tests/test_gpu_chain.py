@@ -57,7 +57,7 @@ def test_chain_vs_oracle_and_launch_per_step_path(gp, oracle, Nl, kname, mb):
     ref, rinfo = oracle.loglik_batch(kname, t, y, s, delays[:nref], alpha[:nref], rho[:nref], mb, nthreads=8)
     assert (rinfo == 0).all()
     with gp.Objective(t, y, s, kname, marginalise_b=mb, slots_per_stream=16) as obj:
-        assert obj.get_option("chain_max") == 12 and obj.get_option("chain_work_max") == 4096
+        assert obj.get_option("chain_max") == 16 and obj.get_option("chain_work_max") == 4096 and obj.get_option("chain_wide_work_max") == 1024
         obj.set_option("chain_work_max", 1 << 30)   # (the kernel itself is under test: every group size takes it)
         out = {}
         for m in (1, 2, 5, 12):
@@ -150,7 +150,7 @@ def test_chain_is_fp64_only_and_other_paths_unchanged(gp, oracle):
         bad[1, 0] = -1.0   # an argument error beside valid evaluations comes back as the fp64 handle reports it
         llb, infob = obj.loglik_batch(d, bad, R3)
         assert infob[1] == -1 and np.isnan(llb[1]) and infob[0] == 0 and infob[2] == 0 and llb[0] == ll64[0]
-        M = 13              # above chain_max: fp32 tiles as before
+        M = 17              # above chain_max: fp32 tiles as before
         dd = np.stack([np.zeros(M), np.linspace(0, 6, M)], 1)
         before = obj.get_option("fp32_chain_count")
         ll13, info13 = obj.loglik_batch(dd, np.tile(alpha, (M, 1)), np.full(M, rho))
@@ -160,27 +160,34 @@ def test_chain_is_fp64_only_and_other_paths_unchanged(gp, oracle):
         assert obj.get_option("fp32_chain_count") == before and (info32 == 0).all() and _rel(ll32, ref) <= 1e-3
         assert not np.array_equal(ll32, ll64)
     with gp.Objective(t, y, s, "matern32", slots_per_stream=32) as obj:
-        M = 13
+        M = 17
         dd = np.stack([np.zeros(M), np.linspace(0, 6, M)], 1)
         ll13, info = obj.loglik_batch(dd, np.tile(alpha, (M, 1)), np.full(M, rho))
         assert obj.get_option("chain_count") == 0 and (info == 0).all()
         ll12, _ = obj.loglik_batch(dd[:12], np.tile(alpha, (12, 1)), np.full(12, rho))
         assert obj.get_option("chain_count") == 12
         assert _rel(ll12, ll13[:12]) <= 1e-11
+        ll16, info16 = obj.loglik_batch(dd[:16], np.tile(alpha, (16, 1)), np.full(16, rho))   # 13 .. 16 evaluations at N <= 1024: the launch too
+        assert obj.get_option("chain_count") == 28 and (info16 == 0).all() and np.array_equal(ll16[:12], ll12)
+        obj.set_option("chain_max", 12)
+        ll16b, _ = obj.loglik_batch(dd[:16], np.tile(alpha, (16, 1)), np.full(16, rho))       # ... or, as before, two halves on two streams
+        assert obj.get_option("chain_count") == 28 and _rel(ll16b, ll16) <= 1e-11
+        obj.set_option("chain_max", 16)
         K = obj.model_matrix(d[0], alpha, rho)
         assert np.array_equal(K, K.T)
         Lf, finfo = obj.factor(d[0], alpha, rho)
-        assert finfo == 0 and obj.get_option("chain_count") == 12
+        assert finfo == 0 and obj.get_option("chain_count") == 28
 
 
 def test_chain_default_policy(gp):
-    """Which groups take the persistent launch by default: at most chain_max = 12 evaluations AND evaluations x (N/128)^2 <= chain_work_max
-    = 4096 -- 4 evaluations at N = 4096, 12 at N = 2048 (profiles/r05/latency_small_batches.log: above, the launch-per-step path is faster)."""
+    """Which groups take the persistent launch by default: up to 12 evaluations while evaluations x (N/128)^2 <= chain_work_max = 4096 -- 4
+    evaluations at N = 4096, 12 at N = 2048 (profiles/r05/latency_small_batches.log: above, the launch-per-step path is faster) -- and
+    13 .. chain_max = 16 while <= chain_wide_work_max = 1024 (N <= 1024; chain_13_to_16_evaluations_ab.log)."""
     from gpcc_amd import synthetic
-    for Nb, takes, not_any_more in ((2048, 4, 5), (1024, 12, 13)):
+    for Nb, takes, not_any_more in ((2048, 4, 5), (1024, 12, 13), (768, 12, 13), (512, 16, 17), (400, 16, 17)):
         t, y, s, _ = synthetic.simulate_lightcurves([Nb, Nb], seed=5)
         alpha, rho = synthetic.default_hyperparameters(y)
-        with gp.Objective(t, y, s, "matern32", slots_per_stream=16) as obj:
+        with gp.Objective(t, y, s, "matern32", slots_per_stream=32) as obj:
             for M, expect in ((takes, takes), (not_any_more, 0)):
                 dd = np.stack([np.zeros(M), np.linspace(0, 3, M)], 1)
                 before = obj.get_option("chain_count")
@@ -202,12 +209,16 @@ def test_chain_many_calls_and_two_streams(gp):
     t, y, s, _ = synthetic.simulate_lightcurves([320, 320], seed=8)
     alpha, rho = synthetic.default_hyperparameters(y)
     with gp.Objective(t, y, s, "matern32", slots_per_stream=16, streams=2) as obj:
-        M = 16 * 3 + 5     # groups of 16, 16, 16 and 5: the last one takes the persistent launch
+        M = 16 * 3 + 5     # groups of 16, 16, 16 and 5 on alternating workspace streams (each with its own flag words): all four are persistent launches
         dd = np.stack([np.zeros(M), np.linspace(0, 9, M)], 1)
-        ll, info = obj.loglik_batch(dd, np.tile(alpha, (M, 1)), np.full(M, rho))
-        assert (info == 0).all() and obj.get_option("chain_count") == 5
+        rr = rho * np.linspace(0.9, 1.1, M)   # (distinct hyper-parameters: a fixed-hyper sweep would share its prefix tiles instead)
+        ll, info = obj.loglik_batch(dd, np.tile(alpha, (M, 1)), rr)
+        assert (info == 0).all() and obj.get_option("chain_count") == M
+        obj.set_option("chain_max", 12)   # only the last group
+        ll12, info = obj.loglik_batch(dd, np.tile(alpha, (M, 1)), rr)
+        assert (info == 0).all() and obj.get_option("chain_count") == M + 5 and _rel(ll12, ll) <= 1e-11
         obj.set_option("chain_max", 0)
-        ll0, _ = obj.loglik_batch(dd, np.tile(alpha, (M, 1)), np.full(M, rho))
+        ll0, _ = obj.loglik_batch(dd, np.tile(alpha, (M, 1)), rr)
         assert _rel(ll, ll0) <= 1e-11
         obj.set_option("chain_max", 12)
         first = None
