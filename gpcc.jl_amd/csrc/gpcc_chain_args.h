@@ -5,7 +5,7 @@
 #include "gpcc_chain_queue.h"
 
 
-#define GPCC_CHAIN_MAX_EVALS 16
+#define GPCC_CHAIN_MAX_EVALS 32
 #define GPCC_CHAIN_MAXRHS 4
 #define GPCC_XIMG_STRIDE (GPCC_XIMG_ELEMS + 16 * GPCC_TILE)   /* doubles per (evaluation, step): the published blocks of L_kk, then S7 (gpcc_chain_trsmq) */
 #define GPCC_XIMG_ELEMS (36 * 256)         /* the lower 36 blocks of inv(L_kk), 16 x 16 row-major each */

@@ -121,9 +121,10 @@ struct gpcc_handle_s {
                              // profiles/r03/two_streams_ab.log); a batch of one group is unaffected
     int slots_per_stream = 256, right_looking_max = GPCC_RIGHT_LOOKING_MAX;
     int fused_small_max = 12;  // groups of at most this many evaluations run gpcc_small_step (update + next diagonal step in one launch)
-    int chain_max = 16;        // option "chain_max": groups of at most this many evaluations run as ONE persistent launch (gpcc_chain.hip.h; fp64 handles, fp32 ones through their twin) where
+    int chain_max = 32;        // option "chain_max": groups of at most this many evaluations run as ONE persistent launch (gpcc_chain.hip.h; fp64 handles, fp32 ones through their twin) where
                                // the policy below says it wins; 0 = never
-    long chain_wide_work_max = 1024; // option "chain_wide_work_max": ... groups of 13 .. chain_max evaluations: evaluations x (N/128)^2 at most this (N <= 1024)
+    long chain_wide_work_max = 1024; // option "chain_wide_work_max": ... groups of 13 .. chain_max evaluations: evaluations x (N/128)^2 at most this (32 at N <= 512, 28 at N = 768,
+                                     // 16 at N = 1024)
     std::atomic<long> chain_count{0};   // evaluations that took the persistent launch so far ("chain_count")
     long chain_work_max = 4096; // option "chain_work_max": ... and at most this many evaluations x tile-steps^2 (12 at N <= 2048, 4 at N = 4096: above, the
                                 // launch-per-step path is the faster one -- profiles/r05/latency_small_batches.log)
@@ -725,10 +726,11 @@ static int ensure_chain(gpcc_handle_t h)
 }
 
 // a group of a few evaluations (one objective(alpha, rho)) on an fp64 handle's own workspace: the persistent launch
-// which group sizes the persistent launch wins at (profiles/r05/latency_small_batches.log, chain_13_to_16_evaluations_ab.log): up to 12
-// evaluations while evaluations x (N/128)^2 <= chain_work_max; 13 .. chain_max while <= chain_wide_work_max (N <= 1024: there the
-// alternative -- two halves on two streams -- is slower even when the halves overlap, and they only overlap when the runtime happens to
-// map the two streams onto different hardware queues: 0.45 against 0.52 / 0.89 ms for 13 evaluations at N = 1024)
+// which group sizes the persistent launch wins at (profiles/r05/latency_small_batches.log, chain_13_to_32_evaluations_ab.log): up to 12
+// evaluations while evaluations x (N/128)^2 <= chain_work_max; 13 .. chain_max = 32 while <= chain_wide_work_max (32 evaluations at
+// N <= 512, 28 at N = 768, 16 at N = 1024: there the alternative -- two halves on two streams -- is slower even when the halves overlap,
+// and they only overlap when the runtime happens to map the two streams onto different hardware queues: 0.45 against 0.52 / 0.89 ms
+// for 13 evaluations at N = 1024, 0.25 against 0.34 for 32 at N = 512)
 static bool chain_policy(gpcc_handle_t h, int cnt, int nt)
 {
     if (h->chain_max <= 0 || cnt > h->chain_max || cnt > GPCC_CHAIN_MAX_EVALS || nt <= 1) return false;
@@ -1287,7 +1289,7 @@ static bool fp32_call_goes_to_fp64_chain(gpcc_handle_t h, int M)
 
 static int fp32_prepare_fp64_chain(gpcc_handle_t h, int M)
 {
-    int rc = ensure_fb(h, 16);
+    int rc = ensure_fb(h, M <= 16 ? 16 : (M + 7) / 8 * 8);   // (one group of the twin's workspace)
     if (rc) return rc;
     h->fb->chain_max = h->chain_max;   // the twin follows this handle's few-evaluation options
     h->fb->chain_work_max = h->chain_work_max;
@@ -1493,7 +1495,9 @@ extern "C" int gpcc_loglik_batch(gpcc_handle_t h, int M, const double *delays, c
         // pinned, device-mapped host memory by the kernels themselves: no copy calls, no events (the general path below costs ~50 us
         // more per call in runtime calls alone -- a quarter of an evaluation at N = 512)
         int rc = ensure_workspace(h);
-        if (!rc) rc = ensure_chain(h);
+        if (rc) return rc;
+        if (M <= h->ws_slots) {   // (one group: a workspace of fewer slots takes the general path below, group by group)
+        rc = ensure_chain(h);
         if (!rc) rc = ensure_lane(h, 0, M);
         if (rc) return rc;
         SmallLane &ln = h->lanes[0];
@@ -1517,6 +1521,7 @@ extern "C" int gpcc_loglik_batch(gpcc_handle_t h, int M, const double *delays, c
                     return fail(h, GPCC_ERR_STATE, "the persistent few-evaluation launch was abandoned (a bounded wait expired: evaluation %d); "
                                                    "gpcc_set_option(handle, \"chain_max\", 0) selects the launch-per-step path", i);
             return 0;
+        }
         }
     }
     int rc = enqueue_host_batch(h, M, delays, alpha, rho, nullptr, nullptr);

@@ -99,14 +99,15 @@ int gpcc_multi_stats(gpcc_handle_t handle, double *compute_ms, double *gather_ms
  *   -----------------------  -------  ---------------------------------------------------------------------------------------------
  *   streams                  2        groups of a batch alternate between this many HIP streams
  *   slots_per_stream         256      evaluations resident per group (fewer where 256 slots exceed 55 % of the device's memory)
- *   chain_max                16       groups of at most this many evaluations at N >= 384 -- a single objective(alpha, rho),
+ *   chain_max                32       groups of at most this many evaluations at N >= 384 -- a single objective(alpha, rho),
  *                                     marginaliseb.jl:133-141 called from Optim's loop, :209-211 -- run as ONE persistent launch
  *                                     (gpcc_chain: two chain workgroups per evaluation carry diagonal step -> column solve -> next
  *                                     diagonal tile without leaving their CUs, all other CUs pull trailing-update jobs; fp64 handles);
  *                                     0 = the two-launches-per-step path below
  *   chain_work_max           4096     ... up to 12 evaluations: and evaluations x (N/128)^2 at most this (12 evaluations up to N = 2048, 4 at
  *                                     N = 4096: above, the path below is faster)
- *   chain_wide_work_max      1024     ... 13 .. chain_max evaluations: and evaluations x (N/128)^2 at most this (N <= 1024: there the alternative,
+ *   chain_wide_work_max      1024     ... 13 .. chain_max evaluations: and evaluations x (N/128)^2 at most this (32 at N <= 512, 28 at N = 768, 16 at
+ *                                     N = 1024: there the alternative,
  *                                     two halves on two streams, is slower even when the halves do overlap -- and they only do when the
  *                                     runtime maps the two streams onto different hardware queues)
  *   chain_workers_max        0        ... at most this many worker workgroups per launch (0 = as many as the widest step has jobs, up to the

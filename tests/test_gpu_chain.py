@@ -57,7 +57,7 @@ def test_chain_vs_oracle_and_launch_per_step_path(gp, oracle, Nl, kname, mb):
     ref, rinfo = oracle.loglik_batch(kname, t, y, s, delays[:nref], alpha[:nref], rho[:nref], mb, nthreads=8)
     assert (rinfo == 0).all()
     with gp.Objective(t, y, s, kname, marginalise_b=mb, slots_per_stream=16) as obj:
-        assert obj.get_option("chain_max") == 16 and obj.get_option("chain_work_max") == 4096 and obj.get_option("chain_wide_work_max") == 1024
+        assert obj.get_option("chain_max") == 32 and obj.get_option("chain_work_max") == 4096 and obj.get_option("chain_wide_work_max") == 1024
         obj.set_option("chain_work_max", 1 << 30)   # (the kernel itself is under test: every group size takes it)
         out = {}
         for m in (1, 2, 5, 12):
@@ -150,7 +150,7 @@ def test_chain_is_fp64_only_and_other_paths_unchanged(gp, oracle):
         bad[1, 0] = -1.0   # an argument error beside valid evaluations comes back as the fp64 handle reports it
         llb, infob = obj.loglik_batch(d, bad, R3)
         assert infob[1] == -1 and np.isnan(llb[1]) and infob[0] == 0 and infob[2] == 0 and llb[0] == ll64[0]
-        M = 17              # above chain_max: fp32 tiles as before
+        M = 21              # beyond the policy (21 x 7^2 > 1024): fp32 tiles as before
         dd = np.stack([np.zeros(M), np.linspace(0, 6, M)], 1)
         before = obj.get_option("fp32_chain_count")
         ll13, info13 = obj.loglik_batch(dd, np.tile(alpha, (M, 1)), np.full(M, rho))
@@ -160,19 +160,19 @@ def test_chain_is_fp64_only_and_other_paths_unchanged(gp, oracle):
         assert obj.get_option("fp32_chain_count") == before and (info32 == 0).all() and _rel(ll32, ref) <= 1e-3
         assert not np.array_equal(ll32, ll64)
     with gp.Objective(t, y, s, "matern32", slots_per_stream=32) as obj:
-        M = 17
+        M = 21
         dd = np.stack([np.zeros(M), np.linspace(0, 6, M)], 1)
         ll13, info = obj.loglik_batch(dd, np.tile(alpha, (M, 1)), np.full(M, rho))
         assert obj.get_option("chain_count") == 0 and (info == 0).all()
         ll12, _ = obj.loglik_batch(dd[:12], np.tile(alpha, (12, 1)), np.full(12, rho))
         assert obj.get_option("chain_count") == 12
         assert _rel(ll12, ll13[:12]) <= 1e-11
-        ll16, info16 = obj.loglik_batch(dd[:16], np.tile(alpha, (16, 1)), np.full(16, rho))   # 13 .. 16 evaluations at N <= 1024: the launch too
+        ll16, info16 = obj.loglik_batch(dd[:16], np.tile(alpha, (16, 1)), np.full(16, rho))   # 13 .. 20 evaluations at N = 800: the launch too
         assert obj.get_option("chain_count") == 28 and (info16 == 0).all() and np.array_equal(ll16[:12], ll12)
         obj.set_option("chain_max", 12)
         ll16b, _ = obj.loglik_batch(dd[:16], np.tile(alpha, (16, 1)), np.full(16, rho))       # ... or, as before, two halves on two streams
         assert obj.get_option("chain_count") == 28 and _rel(ll16b, ll16) <= 1e-11
-        obj.set_option("chain_max", 16)
+        obj.set_option("chain_max", 32)
         K = obj.model_matrix(d[0], alpha, rho)
         assert np.array_equal(K, K.T)
         Lf, finfo = obj.factor(d[0], alpha, rho)
@@ -182,12 +182,12 @@ def test_chain_is_fp64_only_and_other_paths_unchanged(gp, oracle):
 def test_chain_default_policy(gp):
     """Which groups take the persistent launch by default: up to 12 evaluations while evaluations x (N/128)^2 <= chain_work_max = 4096 -- 4
     evaluations at N = 4096, 12 at N = 2048 (profiles/r05/latency_small_batches.log: above, the launch-per-step path is faster) -- and
-    13 .. chain_max = 16 while <= chain_wide_work_max = 1024 (N <= 1024; chain_13_to_16_evaluations_ab.log)."""
+    13 .. chain_max = 32 while <= chain_wide_work_max = 1024 (32 at N <= 512, 16 at N = 1024; chain_13_to_32_evaluations_ab.log)."""
     from gpcc_amd import synthetic
-    for Nb, takes, not_any_more in ((2048, 4, 5), (1024, 12, 13), (768, 12, 13), (512, 16, 17), (400, 16, 17)):
+    for Nb, takes, not_any_more in ((2048, 4, 5), (1024, 12, 13), (768, 12, 13), (512, 16, 17), (400, 20, 21), (220, 32, 33)):
         t, y, s, _ = synthetic.simulate_lightcurves([Nb, Nb], seed=5)
         alpha, rho = synthetic.default_hyperparameters(y)
-        with gp.Objective(t, y, s, "matern32", slots_per_stream=32) as obj:
+        with gp.Objective(t, y, s, "matern32", slots_per_stream=40) as obj:
             for M, expect in ((takes, takes), (not_any_more, 0)):
                 dd = np.stack([np.zeros(M), np.linspace(0, 3, M)], 1)
                 before = obj.get_option("chain_count")
@@ -290,6 +290,25 @@ def test_chain_worker_count_changes_no_bit(gp):
         assert np.array_equal(ll_c, ll) and obj.get_option("chain_last_grid") == full
         with pytest.raises(Exception):
             obj.set_option("chain_workers_max", -1)
+
+
+def test_call_of_more_evaluations_than_workspace_slots(gp):
+    """A handle whose workspace has fewer slots than a call the policy would give to the persistent launch (8 slots, 12 and 30
+    evaluations): the call runs group by group on the general path -- never one launch over more slots than exist."""
+    from gpcc_amd import synthetic
+    t, y, s, _ = synthetic.simulate_lightcurves([260, 250], seed=15)
+    alpha, rho = synthetic.default_hyperparameters(y)
+    M = 30
+    dd = np.stack([np.zeros(M), np.linspace(0.2, 6.0, M)], 1)
+    aa, rr = np.tile(alpha, (M, 1)), rho * np.linspace(0.8, 1.2, M)
+    with gp.Objective(t, y, s, "matern32", slots_per_stream=40) as obj:
+        ref, rinfo = obj.loglik_batch(dd, aa, rr)
+        assert obj.get_option("chain_count") == M and (rinfo == 0).all()
+    with gp.Objective(t, y, s, "matern32", slots_per_stream=8, streams=1) as obj:
+        for m in (12, 30):
+            ll, info = obj.loglik_batch(dd[:m], aa[:m], rr[:m])
+            assert (info == 0).all() and np.array_equal(ll, ref[:m])   # (groups of 8 take the persistent launch one after the other: the same bits)
+        assert obj.get_option("workspace_slots") == 8
 
 
 def test_fp32_multi_device_handle_hands_few_evaluations_to_the_fp64_twins(gp):

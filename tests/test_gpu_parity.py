@@ -753,6 +753,7 @@ def test_shared_prefix_is_bitwise_identical(gp, Nl, prec):
     rhos = np.full(M, rho)
     with gp.Objective(t, y, s, gp.matern32, precision=prec, slots_per_stream=40) as obj:
         assert obj.get_option("share_tiles") == Nl[0] // 128
+        obj.set_option("chain_max", 12)            # (the remainder group of 30 would take the persistent launch at the smallest size: this test compares the tile paths)
         obj.set_option("shared_prefix", 0)
         obj.set_option("hybrid_tail", 0)           # (the right-looking tail sums in another order; the bitwise comparison is between plain left-looking runs)
         dflt, dinfo = obj.loglik_batch(delays, alphas, rhos)     # default plain path: panel solve fused into the update
