@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised soak of the persistent few-evaluation launch: random sizes (2-3 bands, N = 384 .. ~2300), group sizes 1 .. 16, kernels, hyper-parameters
+"""Randomised soak of the persistent few-evaluation launch: random sizes (2-3 bands, N = 384 .. ~2300), group sizes 1 .. 32, kernels, hyper-parameters
 and options (column blocks forced on / off, helper and quarter-job thresholds) -- every result against the launch-per-step path of the same handle
 (chain_max = 0) and repeated once for bits.   python tools/chain_soak.py [--cases 60] [--seed 1] [--nmax 2300]"""
 import argparse
@@ -33,14 +33,14 @@ for case in range(args.cases):
     mb = bool(rng.integers(0, 2))
     t, y, s, _ = synthetic.simulate_lightcurves(Nl, seed=int(rng.integers(1, 1000)))
     alpha, rho = synthetic.default_hyperparameters(y)
-    M = int(rng.integers(1, 17))
+    M = int(rng.integers(1, 33))
     d = np.concatenate([np.zeros((M, 1)), rng.random((M, L - 1)) * 15], 1)
     a = np.tile(alpha, (M, 1)) * (0.6 + 0.8 * rng.random((M, L)))
     r = rho * (0.5 + 1.5 * rng.random(M))
     opts = {"chain_work_max": 1 << 30, "chain_wide_work_max": 1 << 30, "chain_batch_min": int(rng.choice([0, 40000])),
             "chain_batch": int(rng.choice([1, 2, 4, 8])), "chain_helpers_max": int(rng.choice([0, 6, 16])), "chain_quarters_max": int(rng.choice([0, 2, 16])),
             "chain_workers_max": int(rng.choice([0, 0, 3, 40]))}
-    with gpcc_amd.Objective(t, y, s, kname, marginalise_b=mb, slots_per_stream=16, streams=1) as obj:
+    with gpcc_amd.Objective(t, y, s, kname, marginalise_b=mb, slots_per_stream=32, streams=1) as obj:
         for k, v in opts.items():
             obj.set_option(k, v)
         before = obj.get_option("chain_count")
